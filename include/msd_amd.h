@@ -1,0 +1,184 @@
+/*
+ * msd_amd.h -- C ABI of the MI355X-native DDPM spectrogram synthesizer.
+ *
+ * Drop-in boundary for ONE path of magenta/music-spectrogram-diffusion: the
+ * denoising loop reached through InferenceModel.predict
+ * (music_spectrogram_diffusion/inference.py:200-203) ->
+ * {Diffusion,ContextDiffusion}Model.predict_batch_with_aux
+ * (models/diffusion/models.py:149-205, 340-400) ->
+ * diffusion_utils.eval_scan (models/diffusion/diffusion_utils.py:456-476) over
+ * network.{Transformer,ContinuousContextTransformer}.{encode,decode}
+ * (models/diffusion/network.py:460-606).
+ *
+ * The reference is pure Python/JAX: it has no FFI.  These entry points are what
+ * a maintainer would bind (ctypes stub in INTEGRATION.md) to replace the jitted
+ * `predict_fn(params, batch, rng)` of inference.py:183-198 -- one call group per
+ * stage of predict_batch_with_aux.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an msd_status (0 = ok) and never
+ *     throws; msd_last_error() gives the message for the last failure on a handle.
+ *   - one handle <-> one device <-> one caller thread at a time (not re-entrant).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ *     device work is enqueued on it; calls return without synchronising unless
+ *     stated.
+ *   - "dev" pointers are device pointers owned by the caller (e.g. torch
+ *     tensor.data_ptr()); "host" pointers are host memory.  Weights, caches,
+ *     tables and graph objects are owned by the library.
+ *   - tensors are dense row-major; float = IEEE binary32.
+ */
+#ifndef MSD_AMD_H_
+#define MSD_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSD_AMD_ABI_VERSION 1
+
+typedef struct msd_model msd_model; /* opaque */
+
+typedef enum msd_status {
+  MSD_OK = 0,
+  MSD_ERR_INVALID_ARGUMENT = 1, /* -> ValueError (unknown sampler/schedule/...:
+                                   diffusion_utils.py:202,320,450; network.py:106,237,336) */
+  MSD_ERR_UNKNOWN_WEIGHT = 2,   /* -> KeyError */
+  MSD_ERR_SHAPE_MISMATCH = 3,   /* -> ValueError */
+  MSD_ERR_BAD_STATE = 4,        /* call order violated -> RuntimeError */
+  MSD_ERR_HIP = 5,              /* HIP runtime failure -> RuntimeError */
+  MSD_ERR_UNSUPPORTED = 6       /* valid in the reference, not built here -> NotImplementedError */
+} msd_status;
+
+/* Arithmetic of the transformer GEMMs / attention.  Residual stream, RMSNorm
+ * statistics, softmax, FiLM, input/output projections and the sampler are always
+ * fp32 (network.py:454; diffusion_utils.py:461). */
+typedef enum msd_precision {
+  MSD_PREC_BF16 = 0,   /* bf16 MFMA operands, fp32 accumulate                     */
+  MSD_PREC_BF16X3 = 1  /* operands split hi+lo bf16, 3 bf16 MFMAs per product:
+                          ~2^-16 relative error, fp32-class results (parity mode) */
+} msd_precision;
+
+typedef enum msd_sampler_kind {
+  MSD_SAMPLER_DDPM = 0, /* diffusion_utils.py:382-395 */
+  MSD_SAMPLER_DDIM = 1  /* diffusion_utils.py:369-379 */
+} msd_sampler_kind;
+
+/* Hyper-parameters: network.T5Config (network.py:54-72), DiffusionConfig & co
+ * (diffusion_utils.py:25-59), %TASK_FEATURE_LENGTHS (inference.py:97-101) and the
+ * codec range (audio_codecs.py:207-213).  Fixed by construction on this path:
+ * cosine schedules, model_output="eps", logvar_type="large",
+ * decoder_cross_attend_style="concat_encodings", mlp_activations=("gelu","linear"),
+ * head_dim=64; anything else is rejected by the Python layer / msd_create. */
+typedef struct msd_config {
+  int32_t struct_size;            /* sizeof(msd_config), ABI check */
+  int32_t has_context;            /* 0 DiffusionModel, 1 ContextDiffusionModel */
+  int32_t vocab_size;
+  int32_t emb_dim;
+  int32_t num_heads;
+  int32_t head_dim;
+  int32_t mlp_dim;
+  int32_t num_encoder_layers;
+  int32_t num_decoder_layers;
+  int32_t inputs_length;          /* L  */
+  int32_t targets_length;         /* T  */
+  int32_t context_length;         /* C (0 without context) */
+  int32_t n_dims;                 /* mel bins */
+  int32_t num_steps;              /* sampler schedule num_steps */
+  int32_t sampler;                /* msd_sampler_kind */
+  int32_t clip_x0;
+  int32_t context_terminal_relative; /* T5Config.context_positions */
+  int32_t precision;              /* msd_precision */
+  int32_t max_batch;              /* largest `batch` accepted by encode/sample */
+  float max_decoder_noise_time;
+  float cfg_weight;               /* eval_condition_weight; 1.0 = single pass */
+  float feature_min;              /* codec min_value */
+  float feature_max;              /* codec max_value */
+} msd_config;
+
+const char* msd_version(void);
+
+/* Number of visible HIP devices (<0 on failure).  */
+int msd_device_count(void);
+
+/* Create a model on the CURRENT HIP device.  Allocates weights/caches/tables. */
+int msd_create(const msd_config* cfg, msd_model** out);
+void msd_destroy(msd_model* m);
+const char* msd_last_error(const msd_model* m);
+
+/* Parameter tree.  Names are the Flax names of the reference modules, '/'-joined
+ * (e.g. "decoder/layers_3/FiLMLayer_0/DenseGeneral_0/kernel"); shapes as stored
+ * by the reference ([in, out] kernels, layers.py:430-431).  `data` may be host or
+ * device memory (hipMemcpyDefault).  Replaces the params pytree handed to
+ * predict_fn (inference.py:197-203). */
+int msd_num_weights(const msd_model* m);
+int msd_weight_info(const msd_model* m, int index, const char** name, int64_t shape[2], int* ndim);
+int msd_set_weight(msd_model* m, const char* name, const float* data,
+                   const int64_t* shape, int ndim);
+/* Pack weights for the kernels and build every step-indexed table (log-SNR and
+ * sampler coefficients, time-embedding MLP, FiLM scale/bias).  Synchronises. */
+int msd_finalize_weights(msd_model* m, void* stream);
+
+/* module.encode of predict_batch_with_aux (models.py:365-371; network.py:537-559 /
+ * 470-482): runs the token encoder (and context encoder: clip+scale to [-1,1],
+ * models.py:361-363) once and caches the decoder's cross-attention K/V.
+ *   tokens   int32 [batch, L]        (host or device)
+ *   ctx      float [batch, C, n]     mel units (device), NULL without context
+ *   ctx_mask int32 [batch, C]        (host or device), NULL without context   */
+int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_dev,
+               const int32_t* ctx_mask, void* stream);
+
+/* eval_scan (diffusion_utils.py:456-476) + scale_to_features (models.py:395).
+ *   init_z_dev float [batch,T,n] or NULL  -> generated (Philox, see msd_fill_normal)
+ *   noise_dev  float [N,batch,T,n] or NULL -> generated; noise_dev[i] is the draw
+ *              used at scan index i (diffusion_utils.py:389-390)
+ *   seed/stream_id key the generator when a pointer is NULL (stream_id = segment)
+ *   out_dev    float [batch,T,n] mel units                                    */
+int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id,
+               const float* init_z_dev, const float* noise_dev, float* out_dev,
+               void* stream);
+
+/* One decoder call of the scan body: pred_fn(z, time=(i+1)/N, include_conditioning)
+ * (models.py:373-386 -> network.py:561-573).  For parity tests and profiling.
+ *   z_dev float [batch,T,n]; eps_out_dev float [batch,T,n]                     */
+int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev,
+                     int include_conditioning, float* eps_out_dev, void* stream);
+
+/* The library's counter-based normal generator: Philox4x32-10, key
+ * (seed_lo, seed_hi), counter (elem/4, stream_id_lo, stream_id_hi|..., subseq),
+ * Box-Muller; documented in DESIGN.md and restated in oracle/philox.py.
+ * subseq: 0 = init_z, 1 + i = step-i noise.                                   */
+int msd_fill_normal(uint64_t seed, uint64_t stream_id, uint32_t subseq,
+                    float* out_dev, int64_t n, void* stream);
+
+/* Step-indexed tables, for parity tests: copies [num_steps, 8] floats to host:
+ * {logsnr_t, logsnr_s, x0_scale, x0_eps_coef, mean_z_coef, mean_x0_coef, std, 0}. */
+int msd_get_schedule(const msd_model* m, float* host_out);
+
+/* Read an internal buffer as float (bf16 widened) into host memory, for tests.
+ * Returns the element count in *n_out; copies min(count, max_elems).  Synchronises. */
+int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t max_elems,
+                   int64_t* n_out);
+
+/* Per-kernel-class timing of `n_steps` eagerly launched DDPM steps, measured with
+ * hipEvents on `stream` around every launch (bench.py roofline leg).
+ *   names_out  receives a pointer to a static NULL-terminated array of class names
+ *   ms_out / launches_out  [MSD_MAX_KERNEL_CLASSES] totals over the run          */
+#define MSD_MAX_KERNEL_CLASSES 16
+int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** names_out,
+                      double* ms_out, int64_t* launches_out, void* stream);
+
+/* Standalone ops (the building blocks, for unit parity tests). All device ptrs. */
+int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev,
+                     int m, int n, int k, void* stream); /* C = A[m,k] @ W[k,n] */
+int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev,
+                    int m, int n, int k, void* stream);
+int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
+                     const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
+                     int heads, void* stream); /* q [n_q, heads*64], k/v [n_keys, heads*64] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSD_AMD_H_ */

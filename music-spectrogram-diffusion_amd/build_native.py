@@ -1,0 +1,54 @@
+"""Build libmsd_amd.so (HIP/gfx950) in-tree with hipcc.
+
+The shared library is the product's compute path; it is built next to the
+sources (music-spectrogram-diffusion_amd/csrc/libmsd_amd.so) so that it travels
+with the repository snapshot to the GPU box.  ``python -m`` cannot name this
+package (dash), so run:  python music-spectrogram-diffusion_amd/build_native.py
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libmsd_amd.so')
+SOURCES = ['msd_api.hip']
+HEADERS = ['common.h', 'gemm_bf16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
+           os.path.join('..', '..', 'include', 'msd_amd.h')]
+
+
+def _hipcc():
+  for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+    if c and os.path.exists(c):
+      return c
+  raise RuntimeError('hipcc not found (ROCm toolchain required to build the HIP library)')
+
+
+def needs_build() -> bool:
+  if not os.path.exists(LIB):
+    return True
+  t = os.path.getmtime(LIB)
+  for f in SOURCES + HEADERS + [os.path.join('..', 'build_native.py')]:
+    if os.path.getmtime(os.path.join(CSRC, f)) > t:
+      return True
+  return False
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+  if not force and not needs_build():
+    return LIB
+  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+         '-fno-gpu-rdc', '-Wno-unused-result',
+         '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+  if verbose:
+    print('[build_native]', ' '.join(cmd), flush=True)
+  subprocess.run(cmd, check=True, cwd=CSRC)
+  return LIB
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)
+  print(LIB)

@@ -1,0 +1,257 @@
+// Non-GEMM kernels of the path: fused RMSNorm(+FiLM) -> bf16 planes, the fused
+// DDPM/DDIM sampler update, weight packing, embeddings, Philox normal fill.
+#pragma once
+#include "common.h"
+
+namespace msd {
+
+// ---------------------------------------------------------------------------
+// T5 LayerNorm (RMSNorm, eps 1e-6, fp32 statistics; layers.py:632-649) fused
+// with the FiLM modulation x*(scale+1)+bias (layers.py:664-665) whose scale/bias
+// come from the step-indexed table built at load time, and with the cast to the
+// GEMM operand format.  One wave per row, float4 per lane.
+//   film == nullptr     -> plain RMSNorm (cross-attention / encoder / final norm)
+//   film[(step*slots + slot) * 2D + {0..D-1: scale, D..2D-1: bias}]
+// OUT: 0 = bf16 plane, 1 = bf16 hi+lo planes, 2 = fp32
+// ---------------------------------------------------------------------------
+struct NormParams {
+  const float* x;       // [rows, D]
+  const float* gamma;   // [D]
+  const float* film;    // table or nullptr
+  const int* step_ptr;  // device scalar: current scan index i
+  int film_slots, film_slot;
+  int rows, D;
+  bf16_t* out[2];
+  float* out_f32;
+};
+
+template <int OUT, int VPL>  // VPL = float4 loads per lane: D <= 256*VPL
+__global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const float* xr = p.x + (size_t)row * p.D;
+  float4 v[VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < p.D) {
+      v[i] = *reinterpret_cast<const float4*>(xr + c);
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)p.D + 1e-6f);
+  const float* fs = nullptr;
+  if (p.film) fs = p.film + ((size_t)(*p.step_ptr) * p.film_slots + p.film_slot) * (2 * p.D);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < p.D) {
+      const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+      float y[4] = {v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w};
+      if (fs) {
+        const float4 sc = *reinterpret_cast<const float4*>(fs + c);
+        const float4 bi = *reinterpret_cast<const float4*>(fs + p.D + c);
+        y[0] = y[0] * (sc.x + 1.0f) + bi.x;
+        y[1] = y[1] * (sc.y + 1.0f) + bi.y;
+        y[2] = y[2] * (sc.z + 1.0f) + bi.z;
+        y[3] = y[3] * (sc.w + 1.0f) + bi.w;
+      }
+      const size_t off = (size_t)row * p.D + c;
+      if (OUT == 2) {
+        *reinterpret_cast<float4*>(p.out_f32 + off) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (OUT == 1) split_bf16(y[e], h[e], l[e]);
+          else h[e] = f2bf(y[e]);
+        }
+        *reinterpret_cast<uint2*>(p.out[0] + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+        if (OUT == 1)
+          *reinterpret_cast<uint2*>(p.out[1] + off) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused sampler update = everything in eval_step.body after the decoder calls
+// (diffusion_utils.py:416-452): CFG combine, x0-from-eps, clip, posterior mean,
+// + std * noise (DDPM, diffusion_utils.py:120-163,382-395) or the DDIM update
+// (369-379); at scan index 0 returns x0.  Coefficients are per-step scalars from
+// the load-time table (row i of `coef`, see msd_api: kCoef*).  Also advances the
+// device-side scan index so a captured graph can be replayed N times.
+// ---------------------------------------------------------------------------
+enum { kCoefLogsnrT = 0, kCoefLogsnrS, kCoefX0Scale, kCoefX0Eps, kCoefMeanZ, kCoefMeanX0,
+       kCoefStd, kCoefEpsScale, kCoefEpsX0, kCoefAlphaS, kCoefSigmaS, kCoefPad, kCoefCount };
+
+struct SamplerParams {
+  const float* eps;     // [passes][n] decoder outputs (pass 0 = conditional)
+  float* z;             // [n] in/out
+  const float* const* noise_slot;  // device slot holding the [N][n] per-step draws pointer
+  const float* coef;    // [N][kCoefCount]
+  int* step_ptr;        // scan index i (device); decremented by block 0 after use
+  int n;                // batch*T*n_dims
+  int passes;           // 2 with CFG
+  float cond_wt;        // eval_condition_weight
+  int clip_x0, ddim;
+};
+
+__global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
+  const int i = *p.step_ptr;
+  const float* c = p.coef + (size_t)i * kCoefCount;
+  const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx < p.n) {
+    const float4 zz = *reinterpret_cast<const float4*>(p.z + idx);
+    const float4 ec = *reinterpret_cast<const float4*>(p.eps + idx);
+    float4 eu = make_float4(0.f, 0.f, 0.f, 0.f), nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.passes == 2) eu = *reinterpret_cast<const float4*>(p.eps + p.n + idx);
+    if (!p.ddim && i != 0) nz = *reinterpret_cast<const float4*>(*p.noise_slot + (size_t)i * p.n + idx);
+    const float zin[4] = {zz.x, zz.y, zz.z, zz.w}, e0[4] = {ec.x, ec.y, ec.z, ec.w};
+    const float e1[4] = {eu.x, eu.y, eu.z, eu.w}, nn[4] = {nz.x, nz.y, nz.z, nz.w};
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float eps = e0[k];
+      if (p.passes == 2) eps = p.cond_wt * eps + (1.0f - p.cond_wt) * e1[k];
+      float x0 = c[kCoefX0Scale] * (zin[k] - eps * c[kCoefX0Eps]);
+      if (p.clip_x0) {
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        eps = c[kCoefEpsScale] * (zin[k] - x0 * c[kCoefEpsX0]);
+      }
+      float zs;
+      if (p.ddim) zs = c[kCoefAlphaS] * x0 + c[kCoefSigmaS] * eps;
+      else zs = c[kCoefMeanZ] * zin[k] + c[kCoefMeanX0] * x0 + c[kCoefStd] * nn[k];
+      out[k] = (i == 0) ? x0 : zs;
+    }
+    *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+  // every block has read *step_ptr before any kernel of the next step can start
+  // (kernel boundary); the decrement is ordered by the same boundary.
+  __syncthreads();
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) p.step_ptr[1] = i - 1;
+}
+
+// step_ptr[0] <- step_ptr[1]  (double-buffered scan index: the sampler writes the
+// next index to slot 1 while other blocks of the same launch may still read slot 0)
+__global__ void advance_step_kernel(int* step_ptr) { step_ptr[0] = step_ptr[1]; }
+
+// scale_to_features (audio_codecs.py:176-183) on the final x0
+__global__ void unscale_kernel(const float* x0, float* out, int n, float fmin, float fmax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (x0[i] + 1.0f) / 2.0f * (fmax - fmin) + fmin;
+}
+
+// scale_features(clip=True) (audio_codecs.py:166-174) on the context spectrogram
+__global__ void scale_clip_kernel(const float* in, float* out, int n, float fmin, float fmax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float f = fminf(fmaxf(in[i], fmin), fmax);
+    out[i] = (f - fmin) / (fmax - fmin) * 2.0f + (-1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing: W fp32 [K, N] (reference layout, layers.py:430-431) ->
+// W^T bf16 planes [N_out_rows, K]; dst row r takes source column src_col[r]
+// (identity, QKV concatenation, or the 16-column wi_0/wi_1 interleave).
+// ---------------------------------------------------------------------------
+__global__ void pack_wt_kernel(const float* w, int K, int N, bf16_t* hi, bf16_t* lo,
+                               int dst_row0, int col_map_mode, int F) {
+  // grid: (ceil(K/64), N) ; block 64: thread = k within chunk
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  int dst = dst_row0 + n;
+  if (col_map_mode == 1) dst = dst_row0 + (n / 16) * 32 + (n % 16);        // wi_0 of the gated pair
+  else if (col_map_mode == 2) dst = dst_row0 + (n / 16) * 32 + 16 + (n % 16);  // wi_1
+  const float v = w[(size_t)k * N + n];
+  bf16_t h, l;
+  split_bf16(v, h, l);
+  hi[(size_t)dst * K + k] = h;
+  if (lo) lo[(size_t)dst * K + k] = l;
+}
+
+// token embedding (one-hot contraction == row gather, layers.py:556-559) + position
+// table rows (network.py:278-287) for the valid positions of one sequence.
+//   x[r] = tok_emb[tokens[pos[r]]] + pos_emb[pos[r]]   r < n_valid ; 0 for padding rows
+__global__ void embed_tokens_kernel(const int* tokens, const int* pos, int n_valid, int rows,
+                                    const float* tok_emb, const float* pos_emb, float* x, int D) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float v = 0.f;
+    if (r < n_valid) {
+      const int ps = pos[r];
+      v = tok_emb[(size_t)tokens[ps] * D + c] + pos_emb[(size_t)ps * D + c];
+    }
+    x[(size_t)r * D + c] = v;
+  }
+}
+
+// dst[r] = (r < n_valid) ? src[idx[r]] : 0   (row gather with zero padding)
+__global__ void gather_rows_kernel(const float* src, const int* idx, int n_valid, float* dst, int D) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x)
+    dst[(size_t)r * D + c] = (r < n_valid) ? src[(size_t)idx[r] * D + c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller standard normals (documented generator shared with
+// oracle/philox.py).  key = (seed_lo, seed_hi); counter = (block, subseq,
+// stream_lo, stream_hi); element e = 4*block + j, j in 0..3;
+//   u = ((x >> 8) + 0.5) * 2^-24 ; (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+// grid.y = number of consecutive sub-sequences; row y gets subseq0 + y, offset y * n
+__global__ void philox_normal_kernel(float* out, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                                     uint32_t stream_lo, uint32_t stream_hi, uint32_t subseq0) {
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk * 4 >= n) return;
+  out += (int64_t)blockIdx.y * n;
+  uint32_t c[4] = {(uint32_t)blk, subseq0 + blockIdx.y, stream_lo, stream_hi};
+  philox4x32_10(c, seed_lo, seed_hi);
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u0 = ((float)(c[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u1 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float rad = sqrtf(-2.0f * logf(u0));
+    const float ang = 6.283185307179586f * u1;
+    z[2 * h] = rad * cosf(ang);
+    z[2 * h + 1] = rad * sinf(ang);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (blk * 4 + j < n) out[blk * 4 + j] = z[j];
+}
+
+// fp32 -> bf16 planes (test helper for the standalone ops)
+__global__ void split_planes_kernel(const float* in, bf16_t* hi, bf16_t* lo, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    bf16_t h, l;
+    split_bf16(in[i], h, l);
+    hi[i] = h;
+    if (lo) lo[i] = l;
+  }
+}
+__global__ void merge_planes_kernel(const bf16_t* hi, const bf16_t* lo, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = bf2f(hi[i]) + (lo ? bf2f(lo[i]) : 0.f);
+}
+
+}  // namespace msd

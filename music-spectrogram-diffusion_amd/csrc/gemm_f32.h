@@ -1,0 +1,120 @@
+// Exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 for the places the reference keeps in
+// float32 on purpose or where K is tiny:
+//   * spec_out_dense 768->128 "float32 for stability"           (network.py:452-456)
+//   * continuous_inputs_projection / input_proj 128->D          (network.py:420-425, 321-325)
+//   * load-time tables: time-embedding MLP and the 2*Ld FiLM projections for all
+//     N steps at once                                            (network.py:377-392; layers.py:660-663)
+// C[M,N] = A[M,K] . B[K,N], all row-major fp32.  The f32 MFMA is bit-for-bit a
+// k-ordered fmaf chain (MI355X guide), i.e. plain fp32 arithmetic.
+// Block = 4 waves (2x2) on a 64x64 tile, BK = 16, LDS-staged; rows >= M are
+// guarded (M need not be a tile multiple); N % 64 == 0 and K % 16 == 0.
+#pragma once
+#include "common.h"
+
+namespace msd {
+
+struct GemmF32Params {
+  const float* A;
+  const float* B;
+  int lda, ldb;
+  int M, N, K;
+};
+
+struct EpiF32Store {
+  float* out;
+  int ldc;
+  __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ldc + n] = v; }
+};
+struct EpiF32Swish {  // nn.swish (network.py:385,391)
+  float* out;
+  int ldc;
+  __device__ void operator()(int m, int n, float v) const {
+    out[(size_t)m * ldc + n] = v / (1.0f + expf(-v));
+  }
+};
+// decoder input: x[pass][m][:] = z[m] . W_in + pos[m % T]   (network.py:420-427);
+// the same rows feed the conditional and the unconditional pass.
+struct EpiF32InProj {
+  float* x;
+  const float* pos;
+  int ldx, T, pass_stride_rows, passes;
+  __device__ void operator()(int m, int n, float v) const {
+    const float r = v + pos[(size_t)(m % T) * ldx + n];
+    for (int ps = 0; ps < passes; ++ps) x[((size_t)ps * pass_stride_rows + m) * ldx + n] = r;
+  }
+};
+// context encoder input: x[m] = ctx_scaled[m] . W + pos[pos_idx[m]]   (network.py:321-339)
+struct EpiF32AddRows {
+  float* out;
+  const float* table;
+  const int* row_idx;
+  int ldc;
+  __device__ void operator()(int m, int n, float v) const {
+    out[(size_t)m * ldc + n] = v + table[(size_t)row_idx[m] * ldc + n];
+  }
+};
+
+template <class Epi>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Params p, Epi epi) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  __shared__ __attribute__((aligned(16))) float As[BM][BK + 1];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][BN + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = p.N / BN;
+  const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    {  // A tile: 64 x 16 floats = 256 float4
+      const int row = tid >> 2, c4 = (tid & 3) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < p.M) v = *reinterpret_cast<const float4*>(p.A + (size_t)(m0 + row) * p.lda + k0 + c4);
+      As[row][c4] = v.x; As[row][c4 + 1] = v.y; As[row][c4 + 2] = v.z; As[row][c4 + 3] = v.w;
+    }
+    {  // B tile: 16 x 64 floats = 256 float4
+      const int row = tid >> 4, c4 = (tid & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(p.B + (size_t)(k0 + row) * p.ldb + n0 + c4);
+      *reinterpret_cast<float4*>(&Bs[row][c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][kk + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (m < p.M) epi(m, n, acc[i][j][r]);
+      }
+}
+
+template <class Epi>
+inline hipError_t launch_gemm_f32(const GemmF32Params& p, const Epi& epi, hipStream_t stream) {
+  const int grid = ((p.M + 63) / 64) * (p.N / 64);
+  hipLaunchKernelGGL(gemm_f32_kernel<Epi>, dim3(grid), dim3(256), 0, stream, p, epi);
+  return hipGetLastError();
+}
+
+}  // namespace msd

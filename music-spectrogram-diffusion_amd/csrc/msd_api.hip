@@ -1,0 +1,1162 @@
+// C-ABI (include/msd_amd.h) and host runtime of the MI355X DDPM synthesizer:
+// weight store + packing, step-indexed tables, encoder, the per-step kernel chain,
+// hipGraph capture/replay of one DDPM step, profiling.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/msd_amd.h"
+#include "attention.h"
+#include "common.h"
+#include "elementwise.h"
+#include "gemm_bf16.h"
+#include "gemm_f32.h"
+
+using namespace msd;
+
+namespace {
+
+constexpr int kHeadDim = 64;
+
+enum KClass { KC_NORM = 0, KC_GEMM_QKV, KC_ATTN_SELF, KC_GEMM_ATTN_OUT, KC_GEMM_CROSS_Q,
+              KC_ATTN_CROSS, KC_GEMM_CROSS_OUT, KC_GEMM_MLP_IN, KC_GEMM_MLP_OUT,
+              KC_FINAL_PROJ, KC_SAMPLER, KC_IN_PROJ, KC_COUNT };
+const char* const kClassNames[KC_COUNT + 1] = {
+    "rmsnorm_film", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
+    "gemm_cross_out", "gemm_mlp_in_geglu", "gemm_mlp_out", "final_proj_f32", "sampler_step",
+    "in_proj_f32", nullptr};
+
+struct Planes {
+  bf16_t* p[2] = {nullptr, nullptr};
+};
+
+struct Weight {
+  std::string name;
+  int64_t shape[2] = {0, 0};
+  int ndim = 0;
+  float* dev = nullptr;
+  bool set = false;
+  int64_t numel() const { return ndim == 1 ? shape[0] : shape[0] * shape[1]; }
+};
+
+struct AttnW {  // packed attention projections of one layer
+  Planes wqkv;  // self: [3J, D] (q|k|v) ; encoder same
+  Planes wo;    // [D, J]
+};
+struct MlpW {
+  Planes wi;  // [2F, D] wi_0/wi_1 interleaved per 16
+  Planes wo;  // [D, F]
+};
+struct EncLayerW {
+  const float *ln_attn = nullptr, *ln_mlp = nullptr;
+  AttnW attn;
+  MlpW mlp;
+};
+struct DecLayerW {
+  const float *ln_self = nullptr, *ln_cross = nullptr, *ln_mlp = nullptr;
+  AttnW self;
+  Planes wq_cross;   // [J, D]
+  Planes wkv_cross;  // [2J, D] (k|v)
+  Planes wo_cross;   // [D, J]
+  MlpW mlp;
+};
+struct EncoderW {
+  std::vector<EncLayerW> layers;
+  const float* final_ln = nullptr;
+};
+
+struct Profiler {
+  bool on = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double ms[KC_COUNT] = {0};
+  int64_t launches[KC_COUNT] = {0};
+};
+
+}  // namespace
+
+struct msd_model {
+  msd_config cfg;
+  mutable std::string err;
+  int NP = 1;       // bf16 planes per operand
+  int D = 0, J = 0, F = 0, H = 0, T = 0, L = 0, C = 0, ND = 0, N = 0, Ld = 0, Le = 0;
+  int Bmax = 1, passes = 2;
+  int S_pad = 0;    // padded key capacity of the cross-attention cache
+  int Lenc_pad = 0; // padded row capacity of the encoder scratch
+  bool finalized = false, encoded = false;
+  int encoded_batch = 0;
+
+  std::vector<Weight> weights;
+  std::unordered_map<std::string, int> windex;
+  std::vector<void*> allocs;
+
+  EncoderW tok_enc, ctx_enc;
+  std::vector<DecLayerW> dec;
+  const float *dec_final_ln = nullptr, *w_spec_out = nullptr, *w_in_proj = nullptr,
+              *dec_pos = nullptr, *w_ctx_in = nullptr, *ctx_pos = nullptr, *tok_emb = nullptr,
+              *tok_pos = nullptr;
+
+  // tables
+  float* d_coef = nullptr;  // [N][kCoefCount]
+  std::vector<float> h_coef;
+  float* d_film = nullptr;  // [N][2*Ld][2D]
+
+  // decoder activations (rows = passes*Bmax*T)
+  float* x = nullptr;
+  Planes h, qk, vt, ao, cq, g;
+  float* h32 = nullptr;
+  float* eps = nullptr;
+  float* z = nullptr;
+  float* noise_own = nullptr;
+  size_t noise_own_elems = 0;
+  const float** d_noise_slot = nullptr;
+  int* d_step = nullptr;       // [2]
+  int* d_nkeys_self = nullptr; // [passes*Bmax] = T
+  int* d_nkeys_cross = nullptr;// [Bmax]
+  std::vector<int> h_nkeys_cross;
+  Planes kc, vtc;              // cross cache [Ld][Bmax][S_pad][J] / [Ld][Bmax][J][S_pad]
+
+  // encoder scratch (one sequence at a time)
+  float* ex = nullptr;
+  Planes eh, eqk, evt, eao, eg, enc;  // enc = concatenated encodings [S_pad, D]
+  int *d_tokens = nullptr, *d_pos = nullptr, *d_nkeys_enc = nullptr;
+  float *ctx_scaled = nullptr, *ctx_full = nullptr;
+
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_batch = 0;
+  hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
+  Profiler prof;
+};
+
+namespace {
+
+int fail(const msd_model* m, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf;
+  return code;
+}
+
+#define HIP_TRY(m, expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return fail(m, MSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+template <class Tp>
+int dalloc(msd_model* m, Tp** out, size_t count, bool zero = true) {
+  void* p = nullptr;
+  size_t bytes = count * sizeof(Tp);
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(m, hipMalloc(&p, bytes));
+  if (zero) HIP_TRY(m, hipMemset(p, 0, bytes));
+  m->allocs.push_back(p);
+  *out = static_cast<Tp*>(p);
+  return MSD_OK;
+}
+
+int palloc(msd_model* m, Planes* pl, size_t count) {
+  for (int i = 0; i < m->NP; ++i) {
+    int rc = dalloc(m, &pl->p[i], count);
+    if (rc) return rc;
+  }
+  return MSD_OK;
+}
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+void add_weight(msd_model* m, const std::string& name, int64_t a, int64_t b = -1) {
+  Weight w;
+  w.name = name;
+  w.shape[0] = a;
+  w.shape[1] = b < 0 ? 0 : b;
+  w.ndim = b < 0 ? 1 : 2;
+  m->windex[name] = (int)m->weights.size();
+  m->weights.push_back(w);
+}
+
+void declare_weights(msd_model* m) {
+  const int D = m->D, J = m->J, F = m->F;
+  auto attention = [&](const std::string& p) {
+    add_weight(m, p + "/query/kernel", D, J);
+    add_weight(m, p + "/key/kernel", D, J);
+    add_weight(m, p + "/value/kernel", D, J);
+    add_weight(m, p + "/out/kernel", J, D);
+  };
+  auto mlp = [&](const std::string& p) {
+    add_weight(m, p + "/wi_0/kernel", D, F);
+    add_weight(m, p + "/wi_1/kernel", D, F);
+    add_weight(m, p + "/wo/kernel", F, D);
+  };
+  auto encoder_layers = [&](const std::string& p) {
+    for (int l = 0; l < m->Le; ++l) {
+      const std::string lp = p + "/layers_" + std::to_string(l);
+      add_weight(m, lp + "/pre_attention_layer_norm/scale", D);
+      attention(lp + "/attention");
+      add_weight(m, lp + "/pre_mlp_layer_norm/scale", D);
+      mlp(lp + "/mlp");
+    }
+    add_weight(m, p + "/encoder_norm/scale", D);
+  };
+  const std::string tok = m->cfg.has_context ? "token_encoder" : "encoder";
+  add_weight(m, tok + "/token_embedder/embedding", m->cfg.vocab_size, D);
+  add_weight(m, tok + "/Embed_0/embedding", m->L, D);
+  encoder_layers(tok);
+  if (m->cfg.has_context) {
+    add_weight(m, "continuous_encoder/input_proj/kernel", m->ND, D);
+    add_weight(m, "continuous_encoder/Embed_0/embedding", m->C, D);
+    encoder_layers("continuous_encoder");
+  }
+  add_weight(m, "decoder/time_emb_dense0/kernel", D, 4 * D);
+  add_weight(m, "decoder/time_emb_dense1/kernel", 4 * D, 4 * D);
+  add_weight(m, "decoder/Embed_0/embedding", m->T, D);
+  add_weight(m, "decoder/continuous_inputs_projection/kernel", m->ND, D);
+  for (int l = 0; l < m->Ld; ++l) {
+    const std::string lp = "decoder/layers_" + std::to_string(l);
+    add_weight(m, lp + "/pre_self_attention_layer_norm/scale", D);
+    add_weight(m, lp + "/FiLMLayer_0/DenseGeneral_0/kernel", 4 * D, 2 * D);
+    attention(lp + "/self_attention");
+    add_weight(m, lp + "/pre_cross_attention_layer_norm/scale", D);
+    attention(lp + "/MultiHeadDotProductAttention_0");
+    add_weight(m, lp + "/pre_mlp_layer_norm/scale", D);
+    add_weight(m, lp + "/FiLMLayer_1/DenseGeneral_0/kernel", 4 * D, 2 * D);
+    mlp(lp + "/mlp");
+  }
+  add_weight(m, "decoder/decoder_norm/scale", D);
+  add_weight(m, "decoder/spec_out_dense/kernel", D, m->ND);
+}
+
+const float* W(msd_model* m, const std::string& name) { return m->weights[m->windex.at(name)].dev; }
+
+// ---- launch helpers ---------------------------------------------------------
+struct Ctx {
+  msd_model* m;
+  hipStream_t s;
+  hipError_t err = hipSuccess;
+  void begin(int kc) {
+    if (m->prof.on) (void)hipEventRecord(m->prof.e0, s);
+    (void)kc;
+  }
+  void end(int kc) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess && err == hipSuccess) err = e;
+    if (m->prof.on) {
+      (void)hipEventRecord(m->prof.e1, s);
+      (void)hipEventSynchronize(m->prof.e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, m->prof.e0, m->prof.e1);
+      m->prof.ms[kc] += ms;
+      m->prof.launches[kc] += 1;
+    }
+  }
+};
+
+template <int NP>
+GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K) {
+  GemmParams p;
+  for (int i = 0; i < 2; ++i) {
+    p.A[i] = a.p[i < NP ? i : 0];
+    p.B[i] = b.p[i < NP ? i : 0];
+  }
+  p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+
+template <int NP> struct Tile { static constexpr int BK = (NP == 1) ? 64 : 32; };
+
+template <int NP, class Epi>
+void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
+          const Epi& epi) {
+  c.begin(kc);
+  hipError_t e = launch_gemm_bf16<NP, 64, 64, Tile<NP>::BK, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+template <int NP>
+void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const float* film,
+          int slots, int slot, const Planes* out, float* out_f32) {
+  NormParams p;
+  p.x = x; p.gamma = gamma; p.film = film; p.step_ptr = c.m->d_step;
+  p.film_slots = slots; p.film_slot = slot; p.rows = rows; p.D = D;
+  p.out[0] = out ? out->p[0] : nullptr;
+  p.out[1] = out ? out->p[NP - 1] : nullptr;
+  p.out_f32 = out_f32;
+  const dim3 grid((rows + 3) / 4), block(256);
+  c.begin(KC_NORM);
+  const int vpl = (D + 255) / 256;
+#define NORM_LAUNCH(OUT, VPL) hipLaunchKernelGGL((rmsnorm_film_kernel<OUT, VPL>), grid, block, 0, c.s, p)
+  if (out_f32) {
+    if (vpl <= 1) NORM_LAUNCH(2, 1); else if (vpl <= 2) NORM_LAUNCH(2, 2); else if (vpl <= 3) NORM_LAUNCH(2, 3); else NORM_LAUNCH(2, 4);
+  } else if (NP == 2) {
+    if (vpl <= 1) NORM_LAUNCH(1, 1); else if (vpl <= 2) NORM_LAUNCH(1, 2); else if (vpl <= 3) NORM_LAUNCH(1, 3); else NORM_LAUNCH(1, 4);
+  } else {
+    if (vpl <= 1) NORM_LAUNCH(0, 1); else if (vpl <= 2) NORM_LAUNCH(0, 2); else if (vpl <= 3) NORM_LAUNCH(0, 3); else NORM_LAUNCH(0, 4);
+  }
+#undef NORM_LAUNCH
+  c.end(KC_NORM);
+}
+
+template <int NP, int NW>
+void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
+               size_t k_seg_stride, const Planes& vt, int vt_ld, size_t vt_seg_stride,
+               const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
+               int segs) {
+  AttnParams p;
+  for (int i = 0; i < 2; ++i) {
+    const int j = i < NP ? i : 0;
+    p.q[i] = q.p[j]; p.k[i] = k[j]; p.vt[i] = vt.p[j]; p.o[i] = o.p[j];
+  }
+  p.n_keys = n_keys; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
+  p.q_rows_per_seg = q_rows_per_seg; p.k_seg_stride = k_seg_stride;
+  p.vt_seg_stride = vt_seg_stride;
+  c.begin(kc);
+  hipError_t e = launch_attention<NP, NW>(p, q_rows_per_seg / 32, heads, segs, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+template <class Epi>
+void gemm32(Ctx& c, int kc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
+            const Epi& epi) {
+  GemmF32Params p;
+  p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+  c.begin(kc);
+  hipError_t e = launch_gemm_f32(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+// ---- weight packing ----------------------------------------------------------
+int pack(msd_model* m, hipStream_t s, const float* w, int K, int N, Planes& dst, int dst_row0,
+         int mode) {
+  dim3 grid((K + 63) / 64, N), block(64);
+  hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w, K, N, dst.p[0],
+                     m->NP == 2 ? dst.p[1] : (bf16_t*)nullptr, dst_row0, mode, 0);
+  HIP_TRY(m, hipGetLastError());
+  return MSD_OK;
+}
+
+int pack_attention(msd_model* m, hipStream_t s, const std::string& p, AttnW& a) {
+  const int D = m->D, J = m->J;
+  int rc;
+  if ((rc = palloc(m, &a.wqkv, (size_t)3 * J * D))) return rc;
+  if ((rc = palloc(m, &a.wo, (size_t)D * J))) return rc;
+  if ((rc = pack(m, s, W(m, p + "/query/kernel"), D, J, a.wqkv, 0, 0))) return rc;
+  if ((rc = pack(m, s, W(m, p + "/key/kernel"), D, J, a.wqkv, J, 0))) return rc;
+  if ((rc = pack(m, s, W(m, p + "/value/kernel"), D, J, a.wqkv, 2 * J, 0))) return rc;
+  return pack(m, s, W(m, p + "/out/kernel"), J, D, a.wo, 0, 0);
+}
+
+int pack_mlp(msd_model* m, hipStream_t s, const std::string& p, MlpW& w) {
+  const int D = m->D, F = m->F;
+  int rc;
+  if ((rc = palloc(m, &w.wi, (size_t)2 * F * D))) return rc;
+  if ((rc = palloc(m, &w.wo, (size_t)D * F))) return rc;
+  if ((rc = pack(m, s, W(m, p + "/wi_0/kernel"), D, F, w.wi, 0, 1))) return rc;
+  if ((rc = pack(m, s, W(m, p + "/wi_1/kernel"), D, F, w.wi, 0, 2))) return rc;
+  return pack(m, s, W(m, p + "/wo/kernel"), F, D, w.wo, 0, 0);
+}
+
+int pack_encoder(msd_model* m, hipStream_t s, const std::string& p, EncoderW& e) {
+  e.layers.resize(m->Le);
+  for (int l = 0; l < m->Le; ++l) {
+    const std::string lp = p + "/layers_" + std::to_string(l);
+    e.layers[l].ln_attn = W(m, lp + "/pre_attention_layer_norm/scale");
+    e.layers[l].ln_mlp = W(m, lp + "/pre_mlp_layer_norm/scale");
+    int rc;
+    if ((rc = pack_attention(m, s, lp + "/attention", e.layers[l].attn))) return rc;
+    if ((rc = pack_mlp(m, s, lp + "/mlp", e.layers[l].mlp))) return rc;
+  }
+  e.final_ln = W(m, p + "/encoder_norm/scale");
+  return MSD_OK;
+}
+
+// ---- step-indexed tables -------------------------------------------------------
+// diffusion_utils.py:166-187 (cosine), evaluated in float32 like the reference.
+float logsnr_cosine(float t) {
+  const float b = (float)std::atan(std::exp(-0.5 * 20.0));
+  const float a = (float)(std::atan(std::exp(0.5 * 20.0)) - std::atan(std::exp(-0.5 * 20.0)));
+  return -2.0f * std::log(std::tan(a * t + b));
+}
+
+void build_coef_table(msd_model* m) {
+  const int N = m->N;
+  m->h_coef.assign((size_t)N * kCoefCount, 0.f);
+  for (int i = 0; i < N; ++i) {
+    const float t = ((float)i + 1.0f) / (float)N, s = (float)i / (float)N;
+    const float lt = logsnr_cosine(t), ls = logsnr_cosine(s);
+    float* c = &m->h_coef[(size_t)i * kCoefCount];
+    c[kCoefLogsnrT] = lt;
+    c[kCoefLogsnrS] = ls;
+    // predict_x0_from_eps (diffusion_utils.py:215-222)
+    c[kCoefX0Scale] = std::sqrt(1.0f + std::exp(-lt));
+    c[kCoefX0Eps] = 1.0f / std::sqrt(1.0f + std::exp(lt));
+    // diffusion_reverse (diffusion_utils.py:131-147), logvar_type "large"
+    const float alpha_st = std::sqrt((1.0f + std::exp(-lt)) / (1.0f + std::exp(-ls)));
+    const float alpha_s = std::sqrt(1.0f / (1.0f + std::exp(-ls)));
+    const float r = std::exp(lt - ls);
+    const float one_minus_r = -std::expm1(lt - ls);
+    c[kCoefMeanZ] = r * alpha_st;
+    c[kCoefMeanX0] = one_minus_r * alpha_s;
+    c[kCoefStd] = std::sqrt(one_minus_r * (1.0f / (1.0f + std::exp(lt))));
+    // predict_eps_from_x0 (diffusion_utils.py:205-212)
+    c[kCoefEpsScale] = std::sqrt(1.0f + std::exp(lt));
+    c[kCoefEpsX0] = 1.0f / std::sqrt(1.0f + std::exp(-lt));
+    // ddim_step (diffusion_utils.py:376-378)
+    c[kCoefAlphaS] = alpha_s;
+    c[kCoefSigmaS] = std::sqrt(1.0f / (1.0f + std::exp(ls)));
+  }
+}
+
+int build_tables(msd_model* m, hipStream_t s) {
+  const int N = m->N, D = m->D;
+  build_coef_table(m);
+  HIP_TRY(m, hipMemcpyAsync(m->d_coef, m->h_coef.data(), m->h_coef.size() * sizeof(float),
+                            hipMemcpyHostToDevice, s));
+  // time embedding (diffusion_utils.py:69-97 via network.py:377-379), float32
+  std::vector<float> sig((size_t)N * D);
+  const int half = D / 2;
+  const float incr = (float)(std::log((double)m->cfg.max_decoder_noise_time / 1.0) / ((double)half - 1.0));
+  for (int i = 0; i < N; ++i) {
+    const float t = ((float)i + 1.0f) / (float)N;
+    const float pos = t * m->cfg.max_decoder_noise_time;
+    for (int k = 0; k < half; ++k) {
+      const float inv = std::exp((float)k * -incr);
+      const float st = pos * inv;
+      sig[(size_t)i * D + k] = std::sin(st);
+      sig[(size_t)i * D + half + k] = std::cos(st);
+    }
+  }
+  float *d_sig = nullptr, *d_e0 = nullptr, *d_e1 = nullptr;
+  HIP_TRY(m, hipMalloc(&d_sig, sig.size() * sizeof(float)));
+  HIP_TRY(m, hipMalloc(&d_e0, (size_t)N * 4 * D * sizeof(float)));
+  HIP_TRY(m, hipMalloc(&d_e1, (size_t)N * 4 * D * sizeof(float)));
+  HIP_TRY(m, hipMemcpyAsync(d_sig, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  Ctx c{m, s};
+  gemm32(c, KC_IN_PROJ, d_sig, D, W(m, "decoder/time_emb_dense0/kernel"), 4 * D, N, 4 * D, D,
+         EpiF32Swish{d_e0, 4 * D});
+  gemm32(c, KC_IN_PROJ, d_e0, 4 * D, W(m, "decoder/time_emb_dense1/kernel"), 4 * D, N, 4 * D, 4 * D,
+         EpiF32Swish{d_e1, 4 * D});
+  // FiLM scale|bias for every (step, layer, slot): film[i][2l+k][2D]
+  for (int l = 0; l < m->Ld; ++l)
+    for (int k = 0; k < 2; ++k) {
+      const std::string name = "decoder/layers_" + std::to_string(l) + "/FiLMLayer_" +
+                               std::to_string(k) + "/DenseGeneral_0/kernel";
+      gemm32(c, KC_IN_PROJ, d_e1, 4 * D, W(m, name), 2 * D, N, 2 * D, 4 * D,
+             EpiF32Store{m->d_film + (size_t)(2 * l + k) * 2 * D, 2 * m->Ld * 2 * D});
+    }
+  HIP_TRY(m, hipStreamSynchronize(s));
+  (void)hipFree(d_sig); (void)hipFree(d_e0); (void)hipFree(d_e1);
+  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "table build failed: %s", hipGetErrorString(c.err));
+  return MSD_OK;
+}
+
+// ---- encoder ---------------------------------------------------------------------
+template <int NP>
+void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
+  msd_model* m = c.m;
+  const int D = m->D, J = m->J, F = m->F;
+  for (size_t l = 0; l < w.layers.size(); ++l) {
+    const EncLayerW& lw = w.layers[l];
+    norm<NP>(c, m->ex, lw.ln_attn, rows, D, nullptr, 0, 0, &m->eh, nullptr);
+    EpiQKV<NP> eq;
+    eq.qk[0] = m->eqk.p[0]; eq.qk[1] = m->eqk.p[NP - 1];
+    eq.vt[0] = m->evt.p[0]; eq.vt[1] = m->evt.p[NP - 1];
+    eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = m->Lenc_pad; eq.vt_ld = m->Lenc_pad; eq.vt_rows = J;
+    gemm<NP>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq);
+    const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
+    attention<NP, 8>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->evt, m->Lenc_pad, 0, m->eao, J,
+                     m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
+    gemm<NP>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
+    norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
+    EpiGeglu<NP> eg;
+    eg.out[0] = m->eg.p[0]; eg.out[1] = m->eg.p[NP - 1]; eg.ldc = F;
+    gemm<NP>(c, KC_GEMM_MLP_IN, m->eh, D, lw.mlp.wi, D, rows, 2 * F, D, eg);
+    gemm<NP>(c, KC_GEMM_MLP_OUT, m->eg, F, lw.mlp.wo, F, rows, D, F, EpiResidual{m->ex, D});
+  }
+}
+
+template <int NP>
+int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* ctx_dev,
+                const int32_t* ctx_mask_h, hipStream_t s) {
+  const int D = m->D, J = m->J, L = m->L, C = m->C;
+  Ctx c{m, s};
+  std::vector<int> pos;
+  for (int b = 0; b < batch; ++b) {
+    // S3: valid token positions only (mask = tokens > 0, network.py:476/546)
+    pos.clear();
+    for (int i = 0; i < L; ++i)
+      if (tokens_h[(size_t)b * L + i] > 0) pos.push_back(i);
+    const int Lv = (int)pos.size();
+    int Cv = 0;
+    int nk[2] = {Lv, 0};
+    Planes enc_tok = m->enc;  // rows [0, ...)
+    HIP_TRY(m, hipMemsetAsync(m->enc.p[0], 0, (size_t)m->S_pad * D * sizeof(bf16_t), s));
+    if (NP == 2) HIP_TRY(m, hipMemsetAsync(m->enc.p[1], 0, (size_t)m->S_pad * D * sizeof(bf16_t), s));
+    if (Lv > 0) {
+      const int rows = round_up(Lv, 64);
+      HIP_TRY(m, hipMemcpyAsync(m->d_tokens, tokens_h + (size_t)b * L, L * sizeof(int), hipMemcpyHostToDevice, s));
+      HIP_TRY(m, hipMemcpyAsync(m->d_pos, pos.data(), Lv * sizeof(int), hipMemcpyHostToDevice, s));
+      HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_enc, nk, sizeof(int), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(256), 0, s, m->d_tokens, m->d_pos, Lv,
+                         rows, m->tok_emb, m->tok_pos, m->ex, D);
+      encoder_stack<NP>(c, m->tok_enc, rows, 0);
+      norm<NP>(c, m->ex, m->tok_enc.final_ln, rows, D, nullptr, 0, 0, &enc_tok, nullptr);
+      // pageable H2D copies above return after staging, but `pos` is reused below:
+      HIP_TRY(m, hipStreamSynchronize(s));
+    }
+    if (m->cfg.has_context) {
+      pos.clear();
+      const int32_t* cm = ctx_mask_h + (size_t)b * C;
+      for (int i = 0; i < C; ++i)
+        if (cm[i] > 0) pos.push_back(i);
+      Cv = (int)pos.size();
+      if (Cv > 0) {
+        const int rows = round_up(Cv, 64);
+        // positions (network.py:327-334): arange rolled by the sequence length
+        int seq_len = 0;
+        bool any_zero = false;
+        for (int i = 0; i < C; ++i)
+          if (cm[i] == 0) { seq_len = i; any_zero = true; break; }
+        if (!any_zero) seq_len = 0;
+        if (seq_len == 0 && cm[0] != 0) seq_len = C;
+        std::vector<int> pidx(C);
+        for (int i = 0; i < C; ++i) {
+          const int src = m->cfg.context_terminal_relative ? ((i - seq_len) % C + C) % C : i;
+          pidx[i] = src;  // roll(arange, seq_len)[i] = arange[(i - seq_len) mod C]
+        }
+        int* d_pidx = m->d_tokens;  // reuse (C <= L is not guaranteed: sized max(L, C))
+        HIP_TRY(m, hipMemcpyAsync(d_pidx, pidx.data(), C * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(m, hipMemcpyAsync(m->d_pos, pos.data(), Cv * sizeof(int), hipMemcpyHostToDevice, s));
+        nk[1] = Cv;
+        HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_enc + 1, nk + 1, sizeof(int), hipMemcpyHostToDevice, s));
+        const int n = C * m->ND;
+        hipLaunchKernelGGL(scale_clip_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                           ctx_dev + (size_t)b * n, m->ctx_scaled, n, m->cfg.feature_min, m->cfg.feature_max);
+        gemm32(c, KC_IN_PROJ, m->ctx_scaled, m->ND, m->w_ctx_in, D, C, D, m->ND,
+               EpiF32AddRows{m->ctx_full, m->ctx_pos, d_pidx, D});
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, m->ctx_full, m->d_pos, Cv,
+                           m->ex, D);
+        encoder_stack<NP>(c, m->ctx_enc, rows, 1);
+        Planes enc_ctx;
+        enc_ctx.p[0] = m->enc.p[0] + (size_t)Lv * D;
+        enc_ctx.p[1] = NP == 2 ? m->enc.p[1] + (size_t)Lv * D : nullptr;
+        norm<NP>(c, m->ex, m->ctx_enc.final_ln, rows, D, nullptr, 0, 0, &enc_ctx, nullptr);
+        HIP_TRY(m, hipStreamSynchronize(s));
+      }
+    }
+    const int Sv = Lv + Cv;
+    const int Sp = round_up(Sv > 0 ? Sv : 1, 64);
+    // rows [Sv, Sp) may hold normalised padding rows of the last encoder: zero them
+    if (Sp > Sv) {
+      for (int pl = 0; pl < NP; ++pl)
+        HIP_TRY(m, hipMemsetAsync(m->enc.p[pl] + (size_t)Sv * D, 0,
+                                  (size_t)(m->S_pad - Sv) * D * sizeof(bf16_t), s));
+    }
+    // S2: cross-attention K / V^T of every decoder layer, once per segment
+    for (int l = 0; l < m->Ld; ++l) {
+      EpiQKV<NP> ek;
+      const size_t koff = ((size_t)l * m->Bmax + b) * m->S_pad * J;
+      ek.qk[0] = m->kc.p[0] + koff; ek.qk[1] = m->kc.p[NP - 1] + koff;
+      ek.vt[0] = m->vtc.p[0] + koff; ek.vt[1] = m->vtc.p[NP - 1] + koff;
+      ek.ld_qk = J; ek.v_start = J; ek.seg_len = m->S_pad; ek.vt_ld = m->S_pad; ek.vt_rows = J;
+      gemm<NP>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek);
+    }
+    m->h_nkeys_cross[b] = Sv;
+  }
+  HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_cross, m->h_nkeys_cross.data(), batch * sizeof(int),
+                            hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "encode failed: %s", hipGetErrorString(c.err));
+  return MSD_OK;
+}
+
+// ---- one decoder evaluation (network.py:360-457) on rows [0, P*batch*T) ----------
+// pass 0 is conditional iff `cond0`; pass 1 (if P == 2) is the unconditional CFG pass.
+template <int NP>
+void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
+  msd_model* m = c.m;
+  const int D = m->D, J = m->J, F = m->F, T = m->T;
+  const int BT = batch * T, M = P * BT;
+  const int slots = 2 * m->Ld;
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW& w = m->dec[l];
+    // (i) self-attention block (network.py:174-193)
+    norm<NP>(c, m->x, w.ln_self, M, D, m->d_film, slots, 2 * l, &m->h, nullptr);
+    EpiQKV<NP> eq;
+    eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
+    eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
+    eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
+    gemm<NP>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
+    attention<NP, 2>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, m->vt, T,
+                     (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
+    gemm<NP>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
+    // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
+    if (cond0) {
+      norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
+      EpiStoreBf16<NP> es;
+      es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
+      gemm<NP>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
+      const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
+      const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
+      Planes vt;
+      vt.p[0] = m->vtc.p[0] + loff;
+      vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
+      attention<NP, 8>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, vt, m->S_pad,
+                       (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
+      gemm<NP>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
+    }
+    // (iii) MLP block (network.py:241-256)
+    norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
+    EpiGeglu<NP> eg;
+    eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
+    gemm<NP>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
+  }
+  // decoder_norm + spec_out_dense in fp32 (network.py:445-456)
+  norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
+  gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
+}
+
+void in_proj(Ctx& c, int batch, int P) {
+  msd_model* m = c.m;
+  const int BT = batch * m->T;
+  gemm32(c, KC_IN_PROJ, m->z, m->ND, m->w_in_proj, m->D, BT, m->D, m->ND,
+         EpiF32InProj{m->x, m->dec_pos, m->D, m->T, BT, P});
+}
+
+template <int NP>
+void enqueue_step(Ctx& c, int batch) {
+  msd_model* m = c.m;
+  const int P = m->passes;
+  in_proj(c, batch, P);
+  decoder_layers<NP>(c, batch, P, true);
+  SamplerParams sp;
+  sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
+  sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
+  sp.cond_wt = m->cfg.cfg_weight; sp.clip_x0 = m->cfg.clip_x0;
+  sp.ddim = m->cfg.sampler == MSD_SAMPLER_DDIM;
+  c.begin(KC_SAMPLER);
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((sp.n / 4 + 255) / 256), dim3(256), 0, c.s, sp);
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
+  c.end(KC_SAMPLER);
+}
+
+void set_func_attrs() {
+  // large dynamic LDS for the 8-wave attention merge buffer
+  const int smem8 = 8 * (32 * 68 + 64) * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<1, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<2, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+const char* msd_version(void) { return "msd_amd 0.1.0 (gfx950, abi 1)"; }
+
+int msd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+const char* msd_last_error(const msd_model* m) { return m ? m->err.c_str() : "null model"; }
+
+int msd_create(const msd_config* cfg, msd_model** out) {
+  if (!cfg || !out) return MSD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(msd_config)) return MSD_ERR_INVALID_ARGUMENT;
+  msd_model* m = new msd_model();
+  m->cfg = *cfg;
+  auto bad = [&](const char* why) {
+    // keep the handle alive so the caller can read the message
+    m->err = why;
+    *out = m;
+    return MSD_ERR_INVALID_ARGUMENT;
+  };
+  if (cfg->head_dim != kHeadDim) { m->err = "head_dim must be 64"; *out = m; return MSD_ERR_UNSUPPORTED; }
+  if (cfg->precision != MSD_PREC_BF16 && cfg->precision != MSD_PREC_BF16X3) return bad("unknown precision");
+  if (cfg->sampler != MSD_SAMPLER_DDPM && cfg->sampler != MSD_SAMPLER_DDIM) return bad("Unknown sampler type");
+  if (cfg->emb_dim % 64 || cfg->emb_dim > 1024 || cfg->emb_dim < 64) return bad("emb_dim must be a multiple of 64 in [64, 1024]");
+  if (cfg->mlp_dim % 64) return bad("mlp_dim must be a multiple of 64");
+  if (cfg->targets_length % 64 || cfg->targets_length <= 0) return bad("targets length must be a multiple of 64");
+  if (cfg->n_dims % 64) return bad("n_dims must be a multiple of 64");
+  if (cfg->num_steps <= 0 || cfg->max_batch <= 0 || cfg->num_heads <= 0) return bad("non-positive size");
+  if (cfg->has_context && cfg->context_length <= 0) return bad("context model needs context_length");
+  m->NP = cfg->precision == MSD_PREC_BF16X3 ? 2 : 1;
+  m->D = cfg->emb_dim; m->H = cfg->num_heads; m->J = cfg->num_heads * kHeadDim; m->F = cfg->mlp_dim;
+  m->T = cfg->targets_length; m->L = cfg->inputs_length; m->C = cfg->has_context ? cfg->context_length : 0;
+  m->ND = cfg->n_dims; m->N = cfg->num_steps; m->Ld = cfg->num_decoder_layers; m->Le = cfg->num_encoder_layers;
+  m->Bmax = cfg->max_batch;
+  m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
+  m->S_pad = round_up(m->L + m->C, 64);
+  m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
+  declare_weights(m);
+  *out = m;
+  set_func_attrs();
+
+  const int D = m->D, J = m->J, F = m->F, T = m->T;
+  const size_t Mmax = (size_t)m->passes * m->Bmax * T;
+  int rc = MSD_OK;
+#define TRY(e) do { if ((rc = (e)) != MSD_OK) return rc; } while (0)
+  for (auto& w : m->weights) TRY(dalloc(m, &w.dev, (size_t)w.numel()));
+  TRY(dalloc(m, &m->d_coef, (size_t)m->N * kCoefCount));
+  TRY(dalloc(m, &m->d_film, (size_t)m->N * 2 * m->Ld * 2 * D));
+  TRY(dalloc(m, &m->x, Mmax * D));
+  TRY(palloc(m, &m->h, Mmax * D));
+  TRY(palloc(m, &m->qk, Mmax * 2 * J));
+  TRY(palloc(m, &m->vt, Mmax * J));
+  TRY(palloc(m, &m->ao, Mmax * J));
+  TRY(palloc(m, &m->cq, (size_t)m->Bmax * T * J));
+  TRY(palloc(m, &m->g, Mmax * F));
+  TRY(dalloc(m, &m->h32, Mmax * D));
+  TRY(dalloc(m, &m->eps, Mmax * m->ND));
+  TRY(dalloc(m, &m->z, (size_t)m->Bmax * T * m->ND));
+  TRY(dalloc(m, &m->d_noise_slot, 1));
+  TRY(dalloc(m, &m->d_step, 2));
+  TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
+  TRY(dalloc(m, &m->d_nkeys_cross, (size_t)m->Bmax));
+  m->h_nkeys_cross.assign(m->Bmax, 0);
+  {
+    std::vector<int> nk((size_t)m->passes * m->Bmax, T);
+    HIP_TRY(m, hipMemcpy(m->d_nkeys_self, nk.data(), nk.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  TRY(palloc(m, &m->kc, (size_t)m->Ld * m->Bmax * m->S_pad * J));
+  TRY(palloc(m, &m->vtc, (size_t)m->Ld * m->Bmax * m->S_pad * J));
+  const size_t E = m->Lenc_pad;
+  TRY(dalloc(m, &m->ex, E * D));
+  TRY(palloc(m, &m->eh, E * D));
+  TRY(palloc(m, &m->eqk, E * 2 * J));
+  TRY(palloc(m, &m->evt, E * J));
+  TRY(palloc(m, &m->eao, E * J));
+  TRY(palloc(m, &m->eg, E * F));
+  TRY(palloc(m, &m->enc, (size_t)m->S_pad * D));
+  TRY(dalloc(m, &m->d_tokens, E));
+  TRY(dalloc(m, &m->d_pos, E));
+  TRY(dalloc(m, &m->d_nkeys_enc, 2));
+  if (m->cfg.has_context) {
+    TRY(dalloc(m, &m->ctx_scaled, (size_t)m->C * m->ND));
+    TRY(dalloc(m, &m->ctx_full, (size_t)round_up(m->C, 64) * D));
+  }
+#undef TRY
+  HIP_TRY(m, hipEventCreate(&m->prof.e0));
+  HIP_TRY(m, hipEventCreate(&m->prof.e1));
+  HIP_TRY(m, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  return MSD_OK;
+}
+
+void msd_destroy(msd_model* m) {
+  if (!m) return;
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
+  if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  if (m->noise_own) (void)hipFree(m->noise_own);
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+}
+
+int msd_num_weights(const msd_model* m) { return m ? (int)m->weights.size() : -1; }
+
+int msd_weight_info(const msd_model* m, int index, const char** name, int64_t shape[2], int* ndim) {
+  if (!m || index < 0 || index >= (int)m->weights.size()) return MSD_ERR_INVALID_ARGUMENT;
+  const Weight& w = m->weights[index];
+  if (name) *name = w.name.c_str();
+  if (shape) { shape[0] = w.shape[0]; shape[1] = w.shape[1]; }
+  if (ndim) *ndim = w.ndim;
+  return MSD_OK;
+}
+
+int msd_set_weight(msd_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (!m || !name || !data || !shape) return fail(m, MSD_ERR_INVALID_ARGUMENT, "null argument");
+  auto it = m->windex.find(name);
+  if (it == m->windex.end()) return fail(m, MSD_ERR_UNKNOWN_WEIGHT, "unknown weight '%s'", name);
+  Weight& w = m->weights[it->second];
+  bool ok = ndim == w.ndim && shape[0] == w.shape[0] && (ndim == 1 || shape[1] == w.shape[1]);
+  if (!ok)
+    return fail(m, MSD_ERR_SHAPE_MISMATCH, "weight '%s': expected [%lld,%lld] (ndim %d)", name,
+                (long long)w.shape[0], (long long)w.shape[1], w.ndim);
+  HIP_TRY(m, hipMemcpy(w.dev, data, (size_t)w.numel() * sizeof(float), hipMemcpyDefault));
+  w.set = true;
+  m->finalized = false;
+  return MSD_OK;
+}
+
+int msd_finalize_weights(msd_model* m, void* stream) {
+  if (!m) return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (const auto& w : m->weights)
+    if (!w.set) return fail(m, MSD_ERR_BAD_STATE, "weight '%s' was never set", w.name.c_str());
+  if (m->dec.size()) return fail(m, MSD_ERR_BAD_STATE, "weights already finalized (create a new model)");
+  const std::string tok = m->cfg.has_context ? "token_encoder" : "encoder";
+  int rc;
+  if ((rc = pack_encoder(m, s, tok, m->tok_enc))) return rc;
+  m->tok_emb = W(m, tok + "/token_embedder/embedding");
+  m->tok_pos = W(m, tok + "/Embed_0/embedding");
+  if (m->cfg.has_context) {
+    if ((rc = pack_encoder(m, s, "continuous_encoder", m->ctx_enc))) return rc;
+    m->w_ctx_in = W(m, "continuous_encoder/input_proj/kernel");
+    m->ctx_pos = W(m, "continuous_encoder/Embed_0/embedding");
+  }
+  m->dec.resize(m->Ld);
+  const int D = m->D, J = m->J;
+  for (int l = 0; l < m->Ld; ++l) {
+    const std::string lp = "decoder/layers_" + std::to_string(l);
+    DecLayerW& w = m->dec[l];
+    w.ln_self = W(m, lp + "/pre_self_attention_layer_norm/scale");
+    w.ln_cross = W(m, lp + "/pre_cross_attention_layer_norm/scale");
+    w.ln_mlp = W(m, lp + "/pre_mlp_layer_norm/scale");
+    if ((rc = pack_attention(m, s, lp + "/self_attention", w.self))) return rc;
+    const std::string cp = lp + "/MultiHeadDotProductAttention_0";
+    if ((rc = palloc(m, &w.wq_cross, (size_t)J * D))) return rc;
+    if ((rc = palloc(m, &w.wkv_cross, (size_t)2 * J * D))) return rc;
+    if ((rc = palloc(m, &w.wo_cross, (size_t)D * J))) return rc;
+    if ((rc = pack(m, s, W(m, cp + "/query/kernel"), D, J, w.wq_cross, 0, 0))) return rc;
+    if ((rc = pack(m, s, W(m, cp + "/key/kernel"), D, J, w.wkv_cross, 0, 0))) return rc;
+    if ((rc = pack(m, s, W(m, cp + "/value/kernel"), D, J, w.wkv_cross, J, 0))) return rc;
+    if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross, 0, 0))) return rc;
+    if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
+  }
+  m->dec_final_ln = W(m, "decoder/decoder_norm/scale");
+  m->w_spec_out = W(m, "decoder/spec_out_dense/kernel");
+  m->w_in_proj = W(m, "decoder/continuous_inputs_projection/kernel");
+  m->dec_pos = W(m, "decoder/Embed_0/embedding");
+  if ((rc = build_tables(m, s))) return rc;
+  HIP_TRY(m, hipStreamSynchronize(s));
+  m->finalized = true;
+  return MSD_OK;
+}
+
+int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_dev,
+               const int32_t* ctx_mask, void* stream) {
+  if (!m) return MSD_ERR_INVALID_ARGUMENT;
+  if (!m->finalized) return fail(m, MSD_ERR_BAD_STATE, "msd_finalize_weights has not run");
+  if (batch < 1 || batch > m->Bmax) return fail(m, MSD_ERR_INVALID_ARGUMENT, "batch %d outside [1, %d]", batch, m->Bmax);
+  if (!tokens) return fail(m, MSD_ERR_INVALID_ARGUMENT, "tokens is null");
+  if (m->cfg.has_context && (!ctx_dev || !ctx_mask))
+    return fail(m, MSD_ERR_INVALID_ARGUMENT, "context model needs ctx and ctx_mask");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // tokens / mask may live on either side: stage them on the host (a few KiB)
+  std::vector<int32_t> tok_h((size_t)batch * m->L), mask_h;
+  HIP_TRY(m, hipMemcpy(tok_h.data(), tokens, tok_h.size() * sizeof(int32_t), hipMemcpyDefault));
+  if (m->cfg.has_context) {
+    mask_h.resize((size_t)batch * m->C);
+    HIP_TRY(m, hipMemcpy(mask_h.data(), ctx_mask, mask_h.size() * sizeof(int32_t), hipMemcpyDefault));
+  }
+  for (int32_t t : tok_h)
+    if (t < 0 || t >= m->cfg.vocab_size) return fail(m, MSD_ERR_INVALID_ARGUMENT, "token id %d outside [0, %d)", t, m->cfg.vocab_size);
+  int rc = m->NP == 2 ? encode_impl<2>(m, batch, tok_h.data(), ctx_dev, mask_h.data(), s)
+                      : encode_impl<1>(m, batch, tok_h.data(), ctx_dev, mask_h.data(), s);
+  if (rc) return rc;
+  m->encoded = true;
+  m->encoded_batch = batch;
+  return MSD_OK;
+}
+
+int msd_fill_normal(uint64_t seed, uint64_t stream_id, uint32_t subseq, float* out_dev, int64_t n,
+                    void* stream) {
+  if (!out_dev || n < 0) return MSD_ERR_INVALID_ARGUMENT;
+  if (n == 0) return MSD_OK;
+  const int64_t blocks4 = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((blocks4 + 255) / 256), 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), out_dev, n, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), subseq);
+  return hipGetLastError() == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const float* init_z_dev,
+               const float* noise_dev, float* out_dev, void* stream) {
+  if (!m) return MSD_ERR_INVALID_ARGUMENT;
+  if (!m->encoded) return fail(m, MSD_ERR_BAD_STATE, "msd_encode has not run");
+  if (batch != m->encoded_batch) return fail(m, MSD_ERR_INVALID_ARGUMENT, "batch %d != encoded batch %d", batch, m->encoded_batch);
+  if (!out_dev) return fail(m, MSD_ERR_INVALID_ARGUMENT, "out is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool null_stream = (s == nullptr);
+  if (null_stream) {  // the legacy NULL stream cannot be captured: run on our own stream
+    HIP_TRY(m, hipDeviceSynchronize());
+    s = m->own_stream;
+  }
+  const int64_t n = (int64_t)batch * m->T * m->ND;
+  const bool ddpm = m->cfg.sampler == MSD_SAMPLER_DDPM;
+  if (init_z_dev) {
+    HIP_TRY(m, hipMemcpyAsync(m->z, init_z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    int rc = msd_fill_normal(seed, stream_id, 0, m->z, n, s);
+    if (rc) return fail(m, rc, "philox fill failed");
+  }
+  const float* noise = noise_dev;
+  if (ddpm && !noise) {
+    const size_t need = (size_t)m->N * n;
+    if (m->noise_own_elems < need) {
+      if (m->noise_own) (void)hipFree(m->noise_own);
+      m->noise_own = nullptr; m->noise_own_elems = 0;
+      HIP_TRY(m, hipMalloc(&m->noise_own, need * sizeof(float)));
+      m->noise_own_elems = need;
+    }
+    const int64_t blocks4 = (n + 3) / 4;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((blocks4 + 255) / 256), m->N), dim3(256), 0, s,
+                       m->noise_own, n, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id,
+                       (uint32_t)(stream_id >> 32), 1u);
+    HIP_TRY(m, hipGetLastError());
+    noise = m->noise_own;
+  }
+  HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
+  const int start[2] = {m->N - 1, m->N - 1};
+  HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
+
+  if (!m->graph_exec || m->graph_batch != batch) {
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    Ctx c{m, s};
+    if (m->NP == 2) enqueue_step<2>(c, batch); else enqueue_step<1>(c, batch);
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (ce != hipSuccess || c.err != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return fail(m, MSD_ERR_HIP, "graph capture failed: %s / %s", hipGetErrorString(ce), hipGetErrorString(c.err));
+    }
+    hipError_t ie = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { m->graph_exec = nullptr; return fail(m, MSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    m->graph_batch = batch;
+  }
+  for (int i = 0; i < m->N; ++i) HIP_TRY(m, hipGraphLaunch(m->graph_exec, s));
+  hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, out_dev,
+                     (int)n, m->cfg.feature_min, m->cfg.feature_max);
+  HIP_TRY(m, hipGetLastError());
+  if (null_stream) HIP_TRY(m, hipStreamSynchronize(s));
+  return MSD_OK;
+}
+
+int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev,
+                     int include_conditioning, float* eps_out_dev, void* stream) {
+  if (!m) return MSD_ERR_INVALID_ARGUMENT;
+  if (!m->encoded) return fail(m, MSD_ERR_BAD_STATE, "msd_encode has not run");
+  if (batch != m->encoded_batch) return fail(m, MSD_ERR_INVALID_ARGUMENT, "batch != encoded batch");
+  if (step_index < 0 || step_index >= m->N) return fail(m, MSD_ERR_INVALID_ARGUMENT, "step_index outside [0, N)");
+  if (!z_dev || !eps_out_dev) return fail(m, MSD_ERR_INVALID_ARGUMENT, "null buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)batch * m->T * m->ND;
+  const int st[2] = {step_index, step_index};
+  HIP_TRY(m, hipMemcpyAsync(m->d_step, st, sizeof(st), hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipMemcpyAsync(m->z, z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  Ctx c{m, s};
+  in_proj(c, batch, 1);
+  if (m->NP == 2) decoder_layers<2>(c, batch, 1, include_conditioning != 0);
+  else decoder_layers<1>(c, batch, 1, include_conditioning != 0);
+  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "decoder pass failed: %s", hipGetErrorString(c.err));
+  HIP_TRY(m, hipMemcpyAsync(eps_out_dev, m->eps, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return MSD_OK;
+}
+
+int msd_get_schedule(const msd_model* m, float* host_out) {
+  if (!m || !host_out) return MSD_ERR_INVALID_ARGUMENT;
+  if (!m->finalized) return fail(m, MSD_ERR_BAD_STATE, "not finalized");
+  for (int i = 0; i < m->N; ++i) {
+    const float* c = &m->h_coef[(size_t)i * kCoefCount];
+    float* o = host_out + (size_t)i * 8;
+    o[0] = c[kCoefLogsnrT]; o[1] = c[kCoefLogsnrS]; o[2] = c[kCoefX0Scale]; o[3] = c[kCoefX0Eps];
+    o[4] = c[kCoefMeanZ]; o[5] = c[kCoefMeanX0]; o[6] = c[kCoefStd]; o[7] = 0.f;
+  }
+  return MSD_OK;
+}
+
+int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t max_elems, int64_t* n_out) {
+  if (!m || !buffer || !host_out) return MSD_ERR_INVALID_ARGUMENT;
+  const std::string b = buffer;
+  const float* f32 = nullptr;
+  const Planes* pl = nullptr;
+  int64_t count = 0;
+  const int64_t Mmax = (int64_t)m->passes * m->Bmax * m->T;
+  if (b == "film") { f32 = m->d_film; count = (int64_t)m->N * 2 * m->Ld * 2 * m->D; }
+  else if (b == "coef") { f32 = m->d_coef; count = (int64_t)m->N * kCoefCount; }
+  else if (b == "x") { f32 = m->x; count = Mmax * m->D; }
+  else if (b == "eps") { f32 = m->eps; count = Mmax * m->ND; }
+  else if (b == "z") { f32 = m->z; count = (int64_t)m->Bmax * m->T * m->ND; }
+  else if (b == "enc") { pl = &m->enc; count = (int64_t)m->S_pad * m->D; }
+  else if (b == "cross_k") { pl = &m->kc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }
+  else if (b == "cross_vt") { pl = &m->vtc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }
+  else return fail(m, MSD_ERR_INVALID_ARGUMENT, "unknown debug buffer '%s'", buffer);
+  if (n_out) *n_out = count;
+  const int64_t n = count < max_elems ? count : max_elems;
+  if (n <= 0) return MSD_OK;
+  HIP_TRY(m, hipDeviceSynchronize());
+  if (f32) {
+    HIP_TRY(m, hipMemcpy(host_out, f32, n * sizeof(float), hipMemcpyDeviceToHost));
+  } else {
+    float* tmp = nullptr;
+    HIP_TRY(m, hipMalloc(&tmp, n * sizeof(float)));
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, pl->p[0],
+                       m->NP == 2 ? pl->p[1] : (const bf16_t*)nullptr, tmp, n);
+    hipError_t e = hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    HIP_TRY(m, e);
+  }
+  return MSD_OK;
+}
+
+int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** names_out,
+                      double* ms_out, int64_t* launches_out, void* stream) {
+  if (!m || !ms_out || !launches_out) return MSD_ERR_INVALID_ARGUMENT;
+  if (!m->encoded || batch != m->encoded_batch) return fail(m, MSD_ERR_BAD_STATE, "msd_encode (same batch) must run first");
+  if (n_steps < 1 || n_steps > m->N) return fail(m, MSD_ERR_INVALID_ARGUMENT, "n_steps outside [1, N]");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)batch * m->T * m->ND;
+  int rc = msd_fill_normal(1, 0, 0, m->z, n, s);
+  if (rc) return rc;
+  const float* noise = m->noise_own;
+  if (m->cfg.sampler == MSD_SAMPLER_DDPM && m->noise_own_elems < (size_t)m->N * n) {
+    // profile against the z buffer itself as a stand-in noise source is not valid:
+    // allocate the real buffer once.
+    if (m->noise_own) (void)hipFree(m->noise_own);
+    m->noise_own = nullptr; m->noise_own_elems = 0;
+    HIP_TRY(m, hipMalloc(&m->noise_own, (size_t)m->N * n * sizeof(float)));
+    m->noise_own_elems = (size_t)m->N * n;
+    const int64_t blocks4 = (n + 3) / 4;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((blocks4 + 255) / 256), m->N), dim3(256), 0, s,
+                       m->noise_own, n, 1u, 0u, 0u, 0u, 1u);
+    noise = m->noise_own;
+  }
+  HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
+  const int start[2] = {m->N - 1, m->N - 1};
+  HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  for (int k = 0; k < KC_COUNT; ++k) { m->prof.ms[k] = 0; m->prof.launches[k] = 0; }
+  m->prof.on = true;
+  Ctx c{m, s};
+  for (int i = 0; i < n_steps; ++i) {
+    if (m->NP == 2) enqueue_step<2>(c, batch); else enqueue_step<1>(c, batch);
+  }
+  m->prof.on = false;
+  HIP_TRY(m, hipStreamSynchronize(s));
+  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "profile run failed: %s", hipGetErrorString(c.err));
+  for (int k = 0; k < MSD_MAX_KERNEL_CLASSES; ++k) {
+    ms_out[k] = k < KC_COUNT ? m->prof.ms[k] : 0.0;
+    launches_out[k] = k < KC_COUNT ? m->prof.launches[k] : 0;
+  }
+  if (names_out) *names_out = kClassNames;
+  return MSD_OK;
+}
+
+// ---- standalone ops -----------------------------------------------------------------
+extern "C++" {
+namespace {
+struct Scratch {
+  std::vector<void*> p;
+  ~Scratch() { for (void* q : p) (void)hipFree(q); }
+  template <class Tp> Tp* get(size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(Tp) + 16) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, n * sizeof(Tp) + 16);
+    p.push_back(q);
+    return static_cast<Tp*>(q);
+  }
+};
+void split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, hi, lo, n);
+}
+}  // namespace
+}  // extern "C++"
+
+int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev, int M,
+                     int N, int K, void* stream) {
+  if (M % 64 || N % 64 || K % 64 || M <= 0 || N <= 0 || K <= 0) return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int NP = precision == MSD_PREC_BF16X3 ? 2 : 1;
+  Scratch sc;
+  Planes a, w;
+  for (int i = 0; i < NP; ++i) {
+    a.p[i] = sc.get<bf16_t>((size_t)M * K);
+    w.p[i] = sc.get<bf16_t>((size_t)N * K);
+    if (!a.p[i] || !w.p[i]) return MSD_ERR_HIP;
+  }
+  split(a_dev, a.p[0], NP == 2 ? a.p[1] : nullptr, (int64_t)M * K, s);
+  dim3 grid((K + 63) / 64, N), block(64);
+  hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, w.p[0],
+                     NP == 2 ? w.p[1] : (bf16_t*)nullptr, 0, 0, 0);
+  hipError_t e;
+  if (NP == 2) e = launch_gemm_bf16<2, 64, 64, 32>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  else e = launch_gemm_bf16<1, 64, 64, 64>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  if (e != hipSuccess) return MSD_ERR_HIP;
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev, int M, int N, int K,
+                    void* stream) {
+  if (N % 64 || K % 16 || M <= 0) return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GemmF32Params p;
+  p.A = a_dev; p.B = w_dev; p.lda = K; p.ldb = N; p.M = M; p.N = N; p.K = K;
+  if (launch_gemm_f32(p, EpiF32Store{c_dev, N}, s) != hipSuccess) return MSD_ERR_HIP;
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+int msd_op_attention(int precision, const float* q_dev, const float* k_dev, const float* v_dev,
+                     float* o_dev, int n_q, int n_keys, int n_keys_valid, int heads, void* stream) {
+  if (n_q % 32 || n_keys % 32 || n_q <= 0 || n_keys <= 0 || heads <= 0 || n_keys_valid < 0 ||
+      n_keys_valid > n_keys)
+    return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int NP = precision == MSD_PREC_BF16X3 ? 2 : 1;
+  const int J = heads * kHeadDim;
+  Scratch sc;
+  Planes q, k, vt, o;
+  int* d_nk = sc.get<int>(1);
+  float* vt32 = sc.get<float>((size_t)J * n_keys);
+  for (int i = 0; i < NP; ++i) {
+    q.p[i] = sc.get<bf16_t>((size_t)n_q * J);
+    k.p[i] = sc.get<bf16_t>((size_t)n_keys * J);
+    vt.p[i] = sc.get<bf16_t>((size_t)J * n_keys);
+    o.p[i] = sc.get<bf16_t>((size_t)n_q * J);
+    if (!q.p[i] || !k.p[i] || !vt.p[i] || !o.p[i]) return MSD_ERR_HIP;
+  }
+  if (!d_nk || !vt32) return MSD_ERR_HIP;
+  (void)hipMemcpyAsync(d_nk, &n_keys_valid, sizeof(int), hipMemcpyHostToDevice, s);
+  split(q_dev, q.p[0], NP == 2 ? q.p[1] : nullptr, (int64_t)n_q * J, s);
+  split(k_dev, k.p[0], NP == 2 ? k.p[1] : nullptr, (int64_t)n_keys * J, s);
+  // V -> V^T with the per-16 key permutation, via the GEMM epilogue's own rule (host copy)
+  std::vector<float> vh((size_t)n_keys * J), vth((size_t)J * n_keys);
+  if (hipMemcpy(vh.data(), v_dev, vh.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MSD_ERR_HIP;
+  for (int key = 0; key < n_keys; ++key) {
+    const int o16 = key & 15;
+    const int kp = (key & ~15) + 8 * ((o16 >> 2) & 1) + (o16 & 3) + 4 * (o16 >> 3);
+    for (int j = 0; j < J; ++j) vth[(size_t)j * n_keys + kp] = vh[(size_t)key * J + j];
+  }
+  if (hipMemcpy(vt32, vth.data(), vth.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return MSD_ERR_HIP;
+  split(vt32, vt.p[0], NP == 2 ? vt.p[1] : nullptr, (int64_t)J * n_keys, s);
+  AttnParams p;
+  for (int i = 0; i < 2; ++i) {
+    const int j = i < NP ? i : 0;
+    p.q[i] = q.p[j]; p.k[i] = k.p[j]; p.vt[i] = vt.p[j]; p.o[i] = o.p[j];
+  }
+  p.n_keys = d_nk; p.ldq = J; p.ldk = J; p.ldo = J; p.vt_ld = n_keys; p.q_rows_per_seg = n_q;
+  p.k_seg_stride = 0; p.vt_seg_stride = 0;
+  hipError_t e = NP == 2 ? launch_attention<2, 4>(p, n_q / 32, heads, 1, s)
+                         : launch_attention<1, 4>(p, n_q / 32, heads, 1, s);
+  if (e != hipSuccess) return MSD_ERR_HIP;
+  hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
+                     o.p[0], NP == 2 ? o.p[1] : (const bf16_t*)nullptr, o_dev, (int64_t)n_q * J);
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+"""Drop-in mirror of the reference ``inference.py`` for the diffusion path.
+
+Same public surface as the reference (file:line = music_spectrogram_diffusion/):
+  * ``parse_training_gin_file(gin_file, gin_bindings) -> str``      inference.py:32-65
+  * ``InferenceModel(checkpoint_path, gin_config, batch_size=1)``    inference.py:71-111
+      .sequence_length / .inputs_length / .targets_length /
+      .targets_context_length                                        inference.py:97-101
+      .model.FEATURE_CONVERTER_CLS, .audio_codec, .codec, .step      inference.py:104-111,178-181
+      .input_shapes / .input_types                                    inference.py:113-157
+      .predict(batch, seed=0) -> (decodes, scores)                    inference.py:200-203
+plus ``predict_sequence`` -- the per-song segment loop of
+``InferSong.process`` (beam/evaluation.py:161-223) that BASELINE.json's
+north_star names.
+
+The compute is the HIP library behind include/msd_amd.h (native.py); there is
+no fallback.  Differences that a caller can observe, all documented in
+DESIGN.md: (1) the RNG is the library's Philox generator, not jax threefry
+(pass ``init_z``/``noise`` for bit-identical noise across implementations);
+(2) ``checkpoint_path`` accepts ``None`` / ``'synthetic[:seed]'`` (scratch
+init with the reference initialisers, as ``from_checkpoint_or_scratch`` does
+without a checkpoint), a ``.safetensors`` / ``.npz`` flat dict, or an in-memory
+dict -- a T5X/zarr reader is SURVEY.md 8(f) N3.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import audio_codecs
+from . import config as config_lib
+from . import gin_lite
+from . import native
+from . import synthetic
+
+
+def parse_training_gin_file(gin_file: str, gin_bindings: Sequence[str] = ()) -> str:
+  """Parse a T5X training ``.gin`` (with includes) + extra bindings into the flat
+  operative config string ``InferenceModel`` consumes (inference.py:32-65)."""
+  with open(gin_file) as f:
+    text = f.read()
+  roots = [os.path.dirname(os.path.abspath(gin_file)), os.getcwd()]
+  bindings = gin_lite.parse(text, roots)
+  for b in gin_bindings:
+    bindings.update(gin_lite.parse(b, roots))
+  return gin_lite.to_config_str(bindings)
+
+
+class _FeatureConverter:
+  """Stand-in for the seqio feature-converter classes: only the names the model
+  consumes matter at this boundary (models/diffusion/feature_converters.py:32-43,
+  feature_converters.py:35-36)."""
+
+  def __init__(self, model_features):
+    self.MODEL_FEATURES = dict.fromkeys(model_features)
+
+
+class _ModelInfo:
+  """What callers read from ``InferenceModel.model`` (beam/evaluation.py:148)."""
+
+  def __init__(self, spec: config_lib.ModelSpec):
+    self.name = spec.model
+    self.diffusion_config = spec.diffusion
+    if spec.has_context:
+      feats = ['encoder_input_tokens', 'encoder_continuous_inputs', 'encoder_continuous_mask',
+               'decoder_target_tokens', 'decoder_target_mask']
+    else:
+      feats = ['encoder_input_tokens', 'decoder_target_tokens', 'decoder_target_mask']
+    self.FEATURE_CONVERTER_CLS = _FeatureConverter(feats)
+
+
+def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec,
+                      batch_size: int, precision: str) -> native.MsdConfig:
+  t5, d = spec.t5, spec.diffusion
+  # Everything the kernels fix by construction is validated here with the
+  # reference's own error type (ValueError; msd_amd.h msd_config comment).
+  if t5.decoder_cross_attend_style != 'concat_encodings':
+    if t5.decoder_cross_attend_style == 'sum_cross_attends':
+      raise NotImplementedError('decoder_cross_attend_style=sum_cross_attends is not selected '
+                                'by any shipped gin and is not built')
+    raise ValueError(f'Unknown decoder_cross_attend_style: {t5.decoder_cross_attend_style}')
+  if tuple(t5.mlp_activations) != ('gelu', 'linear'):
+    raise NotImplementedError('only gated-GELU MLPs (mlp_activations=(gelu, linear)) are built')
+  if t5.position_encoding not in ('fixed', 'fixed_permuted_offset', 'learnable_permuted_offset',
+                                  'random'):
+    raise ValueError(f'Unknown position_encoding: {t5.position_encoding}')
+  if t5.context_positions not in ('regular', 'terminal_relative'):
+    raise ValueError(f'Unknown context_positions: {t5.context_positions}')
+  if d.sampler.name not in ('ddpm', 'ddim'):
+    raise ValueError('Unknown sampler type: %s' % d.sampler.name)
+  if d.sampler.schedule.name != 'cosine' or d.train_schedule.name != 'cosine':
+    if d.sampler.schedule.name not in ('cosine', 'linear'):
+      raise ValueError('Schedule %s not identified.' % d.sampler.schedule.name)
+    raise NotImplementedError('only the cosine schedule (every shipped gin) is built')
+  if d.model_output != 'eps':
+    if d.model_output not in ('eps', 'x0', 'v', 'x0_and_eps'):
+      raise ValueError('Unknown model_output: %s' % d.model_output)
+    raise NotImplementedError('only model_output="eps" (the reference default) is built')
+  if d.sampler.logvar_type != 'large':
+    raise NotImplementedError('only logvar_type="large" (the reference default) is built')
+  if precision not in native.PRECISIONS:
+    raise ValueError('precision must be one of %s' % sorted(native.PRECISIONS))
+  lens = spec.task_feature_lengths
+  cfg = native.MsdConfig()
+  cfg.has_context = int(spec.has_context)
+  cfg.vocab_size = t5.vocab_size
+  cfg.emb_dim = t5.emb_dim
+  cfg.num_heads = t5.num_heads
+  cfg.head_dim = t5.head_dim
+  cfg.mlp_dim = t5.mlp_dim
+  cfg.num_encoder_layers = t5.num_encoder_layers
+  cfg.num_decoder_layers = t5.num_decoder_layers
+  cfg.inputs_length = lens['inputs']
+  cfg.targets_length = lens['targets']
+  cfg.context_length = lens.get('targets_context', 0) if spec.has_context else 0
+  cfg.n_dims = codec.n_dims
+  cfg.num_steps = d.sampler.schedule.num_steps
+  cfg.sampler = native.MSD_SAMPLER_DDIM if d.sampler.name == 'ddim' else native.MSD_SAMPLER_DDPM
+  cfg.clip_x0 = int(d.sampler.clip_x0)
+  cfg.context_terminal_relative = int(t5.context_positions == 'terminal_relative')
+  cfg.precision = native.PRECISIONS[precision]
+  cfg.max_batch = batch_size
+  cfg.max_decoder_noise_time = t5.max_decoder_noise_time
+  cfg.cfg_weight = d.classifier_free_guidance.eval_condition_weight
+  cfg.feature_min = codec.min_value
+  cfg.feature_max = codec.max_value
+  return cfg
+
+
+def _load_checkpoint(path, spec: config_lib.ModelSpec) -> Tuple[Dict[str, np.ndarray], int]:
+  if isinstance(path, Mapping):
+    return dict(path), 0
+  if path is None or str(path).startswith('synthetic'):
+    seed = 0
+    if path is not None and ':' in str(path):
+      seed = int(str(path).split(':', 1)[1])
+    return synthetic.init_params(spec, seed), 0
+  path = str(path)
+  if path.endswith('.safetensors'):
+    from safetensors.numpy import load_file
+    flat = load_file(path)
+  elif path.endswith('.npz'):
+    with np.load(path) as f:
+      flat = {k: f[k] for k in f.files}
+  else:
+    raise NotImplementedError(
+        'T5X (zarr/tensorstore) checkpoints are not readable here (SURVEY.md 8(f) N3); '
+        'give a .safetensors/.npz flat dict keyed by the Flax parameter names, or '
+        '"synthetic[:seed]"')
+  step = int(np.asarray(flat.pop('__step__', 0)))
+  return {k: np.asarray(v, np.float32) for k, v in flat.items()}, step
+
+
+class InferenceModel(object):
+  """Wrapper of the HIP synthesizer with the reference's InferenceModel API."""
+
+  def __init__(self, checkpoint_path, gin_config: Union[str, config_lib.ModelSpec],
+               batch_size: int = 1, precision: str = 'bf16x3', device: Optional[int] = None):
+    """Args mirror inference.py:71-88.
+
+    gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
+      ``config.ModelSpec`` preset.
+    precision: 'bf16x3' (default; fp32-class results, meets the 1e-3 rms parity
+      bar) or 'bf16' (fastest; does NOT meet the bar).
+    device: HIP device index (default: torch's current device).
+    """
+    import torch  # device memory + streams only
+    if isinstance(gin_config, config_lib.ModelSpec):
+      spec = gin_config
+      self.gin_config = gin_lite.spec_to_config_str(spec)
+    else:
+      self.gin_config = gin_config
+      spec = gin_lite.model_spec_from_bindings(gin_lite.parse(gin_config))
+    self.spec = spec
+    self.checkpoint_path = checkpoint_path
+    self.batch_size = batch_size
+    self.precision = precision
+
+    self.sequence_length = dict(spec.task_feature_lengths)
+    self.inputs_length = self.sequence_length['inputs']
+    self.targets_length = self.sequence_length['targets']
+    self.targets_context_length = self.sequence_length.get('targets_context', None)
+    if spec.has_context and self.targets_context_length is None:
+      raise ValueError('ContextDiffusionModel needs TASK_FEATURE_LENGTHS["targets_context"]')
+    if not spec.has_context:
+      self.targets_context_length = None
+
+    self.model = _ModelInfo(spec)
+    self.audio_codec = audio_codecs.get_codec(spec.audio_codec)
+    self.codec = None  # event codec (vocabularies.build_codec): tokeniser side, SURVEY 8(f) N1
+
+    if not torch.cuda.is_available():
+      raise native.NativeLibraryError(
+          'no HIP device visible: InferenceModel runs only on the GPU (no CPU fallback)')
+    self._torch = torch
+    self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+    self._params_np: Optional[Dict[str, np.ndarray]] = None
+    self._native: Optional[native.NativeModel] = None
+    self._step = 0
+    self._stream = None
+    self.last_timing: Dict[str, float] = {}
+
+  # -- shapes / types (inference.py:113-157) -------------------------------------
+  @property
+  def input_shapes(self):
+    shapes = {
+        'encoder_input_tokens': (self.batch_size, self.inputs_length),
+        'decoder_target_tokens': (self.batch_size, self.targets_length, self.audio_codec.n_dims),
+    }
+    if self.targets_context_length is not None:
+      shapes.update({
+          'encoder_continuous_inputs':
+              (self.batch_size, self.targets_context_length, self.audio_codec.n_dims),
+          'encoder_continuous_mask': (self.batch_size, self.targets_context_length),
+      })
+    if 'decoder_input_tokens' in self.model.FEATURE_CONVERTER_CLS.MODEL_FEATURES:
+      shapes['decoder_input_tokens'] = shapes['decoder_target_tokens']
+    return shapes
+
+  @property
+  def input_types(self):
+    types = {'encoder_input_tokens': np.int32, 'decoder_target_tokens': np.float32}
+    if self.targets_context_length is not None:
+      types.update({'encoder_continuous_inputs': np.float32,
+                    'encoder_continuous_mask': np.int32})
+    if 'decoder_input_tokens' in self.model.FEATURE_CONVERTER_CLS.MODEL_FEATURES:
+      types['decoder_input_tokens'] = types['decoder_target_tokens']
+    return types
+
+  # -- restore (inference.py:159-198): lazy, once per process ----------------------
+  def _get_native(self) -> native.NativeModel:
+    if self._native is None:
+      torch = self._torch
+      with torch.cuda.device(self.device):
+        params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
+        cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision)
+        nm = native.NativeModel(cfg)
+        self._stream = torch.cuda.Stream(device=self.device)
+        nm.load_weights(params, stream=self._stream.cuda_stream)
+        self._params_np = params
+        self._native = nm
+    return self._native
+
+  @property
+  def step(self):
+    self._get_native()
+    return self._step
+
+  @property
+  def params(self) -> Dict[str, np.ndarray]:
+    self._get_native()
+    return self._params_np
+
+  # -- predict (inference.py:200-203) -----------------------------------------------
+  def predict(self, batch: Mapping[str, Any], seed: int = 0, segment: int = 0,
+              init_z=None, noise=None, return_torch: bool = False):
+    """Predict one batch of 256-frame segments.
+
+    batch: the model features of inference.py:113-136 (NumPy arrays or torch
+      tensors); ``decoder_target_tokens`` is used for its shape only.
+    seed / segment: key of the Philox generator (replaces PRNGKey(seed)).
+    init_z [B,T,n] / noise [N,B,T,n]: explicit draws (the parity contract).
+    Returns (decodes float32 [B,T,n] in mel units, scores float32 [B] zeros).
+    """
+    torch = self._torch
+    nm = self._get_native()
+    dev = self.device
+    tokens = np.ascontiguousarray(_to_numpy(batch['encoder_input_tokens']), dtype=np.int32)
+    b = tokens.shape[0]
+    if tokens.ndim != 2 or tokens.shape[1] != self.inputs_length:
+      raise ValueError('encoder_input_tokens must be [batch, %d]' % self.inputs_length)
+    if b > self.batch_size:
+      raise ValueError('batch %d exceeds batch_size %d' % (b, self.batch_size))
+    t, n = self.targets_length, self.audio_codec.n_dims
+    t0 = time.perf_counter()
+    with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+      s = self._stream.cuda_stream
+      ctx = mask = None
+      if self.targets_context_length is not None:
+        ctx = _to_device(torch, batch['encoder_continuous_inputs'], dev, torch.float32)
+        if tuple(ctx.shape) != (b, self.targets_context_length, n):
+          raise ValueError('encoder_continuous_inputs must be [batch, %d, %d]'
+                           % (self.targets_context_length, n))
+        mask = np.ascontiguousarray(_to_numpy(batch['encoder_continuous_mask']), dtype=np.int32)
+      nm.encode(b, tokens, ctx, mask, stream=s)
+      t1 = time.perf_counter()
+      out = torch.empty((b, t, n), dtype=torch.float32, device=dev)
+      z0 = None if init_z is None else _to_device(torch, init_z, dev, torch.float32)
+      nz = None if noise is None else _to_device(torch, noise, dev, torch.float32)
+      if z0 is not None and tuple(z0.shape) != (b, t, n):
+        raise ValueError('init_z must be [batch, %d, %d]' % (t, n))
+      if nz is not None and tuple(nz.shape) != (self.spec.diffusion.sampler.schedule.num_steps, b, t, n):
+        raise ValueError('noise must be [num_steps, batch, %d, %d]' % (t, n))
+      nm.sample(b, out, seed=seed, stream_id=segment, init_z=z0, noise=nz, stream=s)
+      self._stream.synchronize()
+    t2 = time.perf_counter()
+    self.last_timing = {'encode_s': t1 - t0, 'sample_s': t2 - t1, 'total_s': t2 - t0}
+    scores = np.zeros((b,), np.float32)
+    if return_torch:
+      return out, torch.zeros((b,), dtype=torch.float32, device=dev)
+    return out.cpu().numpy(), scores
+
+  # -- InferSong.process segment loop (beam/evaluation.py:161-223) ---------------------
+  def predict_sequence(self, segments_tokens: Sequence[np.ndarray], seed: int = 0,
+                       always_mask_context: bool = False, init_context: Optional[np.ndarray] = None,
+                       first_segment_index: int = 0, return_timing: bool = False):
+    """Synthesize a whole song: segments of int32 [inputs_length] (or [1, L]).
+
+    Segment 0 runs with context zeros + mask 0 (beam/evaluation.py:195-198);
+    segment i > 0 gets the previous PREDICTION (mel units) with mask 1
+    (:194,199-205); ``always_mask_context`` masks every segment (:66-68).
+    ``init_context`` [1, C, n] (+ ``first_segment_index`` > 0) resumes a song in
+    the middle: the chained multi-GPU hand-off (sharding.py) uses it.
+    Returns float32 [1, T*K, n]; with ``return_timing`` also a dict with the
+    reference's own metric (evaluation.py:217-220,244-250).
+    """
+    torch = self._torch
+    n = self.audio_codec.n_dims
+    c_len = self.targets_context_length
+    pred = None
+    if c_len is not None:
+      pred = torch.zeros((1, c_len, n), dtype=torch.float32, device=self.device)
+      if init_context is not None:
+        pred = _to_device(torch, init_context, self.device, torch.float32).reshape(1, c_len, n)
+    outs, seconds = [], []
+    for i, toks in enumerate(segments_tokens):
+      gi = first_segment_index + i
+      toks = np.asarray(toks, np.int32).reshape(1, -1)
+      batch = {'encoder_input_tokens': toks}
+      if c_len is not None:
+        batch['encoder_continuous_inputs'] = pred
+        no_ctx = always_mask_context or (i == 0 and init_context is None)
+        batch['encoder_continuous_mask'] = (np.zeros if no_ctx else np.ones)((1, c_len), np.int32)
+      tick = time.perf_counter()
+      out, _ = self.predict(batch, seed=seed, segment=gi, return_torch=True)
+      if i != 0:
+        seconds.append(time.perf_counter() - tick)
+      if c_len is not None:
+        pred = out[:1]
+      outs.append(out[:1])
+    full = torch.cat(outs, dim=1).cpu().numpy()
+    if not return_timing:
+      return full
+    seconds_per_chunk = self.targets_length * (self.audio_codec.hop_size / self.audio_codec.sample_rate)
+    per_chunk = float(np.mean(seconds)) if seconds else float('nan')
+    return full, {'prediction_seconds_per_chunk': per_chunk,
+                  'predictions_seconds_per_audio_second': per_chunk / seconds_per_chunk}
+
+
+def _to_numpy(x) -> np.ndarray:
+  if isinstance(x, np.ndarray):
+    return x
+  if hasattr(x, 'detach'):
+    return x.detach().cpu().numpy()
+  return np.asarray(x)
+
+
+def _to_device(torch, x, dev, dtype):
+  if isinstance(x, torch.Tensor):
+    return x.to(device=dev, dtype=dtype).contiguous()
+  return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(dev)

@@ -1,0 +1,276 @@
+"""ctypes binding of the C ABI in include/msd_amd.h (libmsd_amd.so).
+
+This is the ONLY compute path of the package: there is no CPU or PyTorch
+fallback.  ``load()`` raises ``NativeLibraryError`` when the HIP library has not
+been built (run ``python music-spectrogram-diffusion_amd/build_native.py`` or
+``__graft_entry__.build()``), and every wrapper converts a non-zero msd_status
+into the Python exception the reference raises for the same condition
+(ValueError for unknown sampler/schedule/..., see msd_amd.h).
+
+PyTorch is plumbing here: device memory (``tensor.data_ptr()``), streams and
+``torch.distributed``; no torch op is on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmsd_amd.so')
+
+MSD_PREC_BF16 = 0
+MSD_PREC_BF16X3 = 1
+MSD_SAMPLER_DDPM = 0
+MSD_SAMPLER_DDIM = 1
+MAX_KERNEL_CLASSES = 16
+
+PRECISIONS = {'bf16': MSD_PREC_BF16, 'bf16x3': MSD_PREC_BF16X3}
+
+# every symbol include/msd_amd.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = (
+    'msd_version', 'msd_device_count', 'msd_create', 'msd_destroy', 'msd_last_error',
+    'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
+    'msd_encode', 'msd_sample', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
+    'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
+    'msd_op_attention')
+
+
+class NativeLibraryError(RuntimeError):
+  pass
+
+
+class MsdConfig(ctypes.Structure):
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
+      'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
+      'targets_length', 'context_length', 'n_dims', 'num_steps', 'sampler', 'clip_x0',
+      'context_terminal_relative', 'precision', 'max_batch')] + [
+          (n, ctypes.c_float) for n in (
+              'max_decoder_noise_time', 'cfg_weight', 'feature_min', 'feature_max')]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+  """dlopen libmsd_amd.so and declare prototypes.  Fails loudly if missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise NativeLibraryError(
+        'HIP library not built: %s is missing. Build it with '
+        '`python music-spectrogram-diffusion_amd/build_native.py` (needs hipcc); '
+        'there is no CPU fallback for this path.' % LIB_PATH)
+  try:
+    lib = ctypes.CDLL(LIB_PATH)
+  except OSError as e:  # missing ROCm runtime etc.
+    raise NativeLibraryError('cannot load %s: %s' % (LIB_PATH, e)) from e
+  for sym in EXPORTED_SYMBOLS:
+    if not hasattr(lib, sym):
+      raise NativeLibraryError('%s does not export %s' % (LIB_PATH, sym))
+  c = ctypes
+  vp, i32, i64, u64, u32 = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_uint32
+  lib.msd_version.restype = c.c_char_p
+  lib.msd_device_count.restype = i32
+  lib.msd_create.argtypes = [c.POINTER(MsdConfig), c.POINTER(vp)]
+  lib.msd_destroy.argtypes = [vp]
+  lib.msd_destroy.restype = None
+  lib.msd_last_error.argtypes = [vp]
+  lib.msd_last_error.restype = c.c_char_p
+  lib.msd_num_weights.argtypes = [vp]
+  lib.msd_weight_info.argtypes = [vp, i32, c.POINTER(c.c_char_p), c.POINTER(i64), c.POINTER(i32)]
+  lib.msd_set_weight.argtypes = [vp, c.c_char_p, vp, c.POINTER(i64), i32]
+  lib.msd_finalize_weights.argtypes = [vp, vp]
+  lib.msd_encode.argtypes = [vp, i32, vp, vp, vp, vp]
+  lib.msd_sample.argtypes = [vp, i32, u64, u64, vp, vp, vp, vp]
+  lib.msd_decoder_pass.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+  lib.msd_fill_normal.argtypes = [u64, u64, u32, vp, i64, vp]
+  lib.msd_get_schedule.argtypes = [vp, vp]
+  lib.msd_debug_read.argtypes = [vp, c.c_char_p, vp, i64, c.POINTER(i64)]
+  lib.msd_profile_steps.argtypes = [vp, i32, i32, c.POINTER(c.POINTER(c.c_char_p)),
+                                    c.POINTER(c.c_double), c.POINTER(i64), vp]
+  lib.msd_op_gemm_bf16.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
+  lib.msd_op_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+  lib.msd_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  for name in EXPORTED_SYMBOLS:
+    fn = getattr(lib, name)
+    if name not in ('msd_version', 'msd_last_error', 'msd_destroy'):
+      fn.restype = i32
+  _lib = lib
+  return lib
+
+
+_EXC = {1: ValueError, 2: KeyError, 3: ValueError, 4: RuntimeError, 5: RuntimeError,
+        6: NotImplementedError}
+
+
+def _check(lib, handle, rc, what):
+  if rc == 0:
+    return
+  msg = lib.msd_last_error(handle).decode('utf-8', 'replace') if handle else ''
+  raise _EXC.get(rc, RuntimeError)('%s failed (msd_status %d): %s' % (what, rc, msg))
+
+
+def _ptr(t) -> Optional[int]:
+  """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+  if t is None:
+    return None
+  if isinstance(t, np.ndarray):
+    return t.ctypes.data
+  return t.data_ptr()
+
+
+class NativeModel:
+  """Owns one ``msd_model*`` on the current HIP device."""
+
+  def __init__(self, cfg: MsdConfig):
+    self.lib = load()
+    self.cfg = cfg
+    self.handle = ctypes.c_void_p()
+    cfg.struct_size = ctypes.sizeof(MsdConfig)
+    rc = self.lib.msd_create(ctypes.byref(cfg), ctypes.byref(self.handle))
+    if rc != 0:
+      msg = self.lib.msd_last_error(self.handle).decode() if self.handle else 'invalid config'
+      if self.handle:
+        self.lib.msd_destroy(self.handle)
+        self.handle = ctypes.c_void_p()
+      raise _EXC.get(rc, RuntimeError)('msd_create failed (msd_status %d): %s' % (rc, msg))
+
+  def close(self):
+    if getattr(self, 'handle', None):
+      self.lib.msd_destroy(self.handle)
+      self.handle = ctypes.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+  # -- weights ---------------------------------------------------------------
+  def weight_specs(self) -> List[Tuple[str, Tuple[int, ...]]]:
+    out = []
+    for i in range(self.lib.msd_num_weights(self.handle)):
+      name = ctypes.c_char_p()
+      shape = (ctypes.c_int64 * 2)()
+      ndim = ctypes.c_int()
+      _check(self.lib, self.handle,
+             self.lib.msd_weight_info(self.handle, i, ctypes.byref(name), shape, ctypes.byref(ndim)),
+             'msd_weight_info')
+      out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value))))
+    return out
+
+  def set_weight(self, name: str, array):
+    """array: float32 numpy array or torch tensor (host or device), C-contiguous."""
+    if isinstance(array, np.ndarray):
+      array = np.ascontiguousarray(array, dtype=np.float32)
+      shape = array.shape
+    else:
+      array = array.contiguous().float()
+      shape = tuple(array.shape)
+    cshape = (ctypes.c_int64 * max(len(shape), 1))(*shape)
+    _check(self.lib, self.handle,
+           self.lib.msd_set_weight(self.handle, name.encode(), _ptr(array), cshape, len(shape)),
+           'msd_set_weight(%s)' % name)
+
+  def load_weights(self, params: Dict[str, np.ndarray], stream: int = 0):
+    specs = dict(self.weight_specs())
+    missing = [k for k in specs if k not in params]
+    if missing:
+      raise KeyError('parameter dict is missing %d weights, e.g. %s' % (len(missing), missing[:3]))
+    for name in specs:
+      self.set_weight(name, params[name])
+    _check(self.lib, self.handle, self.lib.msd_finalize_weights(self.handle, stream),
+           'msd_finalize_weights')
+
+  # -- hot path ----------------------------------------------------------------
+  def encode(self, batch: int, tokens, ctx=None, ctx_mask=None, stream: int = 0):
+    _check(self.lib, self.handle,
+           self.lib.msd_encode(self.handle, batch, _ptr(tokens), _ptr(ctx), _ptr(ctx_mask), stream),
+           'msd_encode')
+
+  def sample(self, batch: int, out, seed: int = 0, stream_id: int = 0, init_z=None,
+             noise=None, stream: int = 0):
+    _check(self.lib, self.handle,
+           self.lib.msd_sample(self.handle, batch, seed, stream_id, _ptr(init_z), _ptr(noise),
+                               _ptr(out), stream), 'msd_sample')
+
+  def decoder_pass(self, batch: int, step_index: int, z, include_conditioning: bool, eps_out,
+                   stream: int = 0):
+    _check(self.lib, self.handle,
+           self.lib.msd_decoder_pass(self.handle, batch, step_index, _ptr(z),
+                                     int(bool(include_conditioning)), _ptr(eps_out), stream),
+           'msd_decoder_pass')
+
+  def schedule(self) -> np.ndarray:
+    out = np.zeros((self.cfg.num_steps, 8), np.float32)
+    _check(self.lib, self.handle, self.lib.msd_get_schedule(self.handle, out.ctypes.data),
+           'msd_get_schedule')
+    return out
+
+  def debug_read(self, buffer: str, max_elems: Optional[int] = None) -> np.ndarray:
+    n = ctypes.c_int64()
+    probe = np.zeros(1, np.float32)
+    _check(self.lib, self.handle,
+           self.lib.msd_debug_read(self.handle, buffer.encode(), probe.ctypes.data, 0, ctypes.byref(n)),
+           'msd_debug_read')
+    count = n.value if max_elems is None else min(n.value, max_elems)
+    out = np.zeros(count, np.float32)
+    _check(self.lib, self.handle,
+           self.lib.msd_debug_read(self.handle, buffer.encode(), out.ctypes.data, count, ctypes.byref(n)),
+           'msd_debug_read')
+    return out
+
+  def profile_steps(self, batch: int, n_steps: int, stream: int = 0) -> Dict[str, Tuple[float, int]]:
+    names = ctypes.POINTER(ctypes.c_char_p)()
+    ms = (ctypes.c_double * MAX_KERNEL_CLASSES)()
+    launches = (ctypes.c_int64 * MAX_KERNEL_CLASSES)()
+    _check(self.lib, self.handle,
+           self.lib.msd_profile_steps(self.handle, batch, n_steps, ctypes.byref(names), ms,
+                                      launches, stream), 'msd_profile_steps')
+    out = {}
+    i = 0
+    while i < MAX_KERNEL_CLASSES and names[i]:
+      out[names[i].decode()] = (float(ms[i]), int(launches[i]))
+      i += 1
+    return out
+
+
+def fill_normal(out, seed: int, stream_id: int, subseq: int, stream: int = 0):
+  lib = load()
+  rc = lib.msd_fill_normal(seed, stream_id, subseq, _ptr(out), out.numel(), stream)
+  if rc:
+    raise RuntimeError('msd_fill_normal failed (%d)' % rc)
+
+
+def op_gemm_bf16(precision: str, a, w, c, stream: int = 0):
+  lib = load()
+  m, k = a.shape
+  n = w.shape[1]
+  rc = lib.msd_op_gemm_bf16(PRECISIONS[precision], _ptr(a), _ptr(w), _ptr(c), m, n, k, stream)
+  if rc:
+    raise _EXC.get(rc, RuntimeError)('msd_op_gemm_bf16 failed (%d)' % rc)
+
+
+def op_gemm_f32(a, w, c, stream: int = 0):
+  lib = load()
+  m, k = a.shape
+  n = w.shape[1]
+  rc = lib.msd_op_gemm_f32(_ptr(a), _ptr(w), _ptr(c), m, n, k, stream)
+  if rc:
+    raise _EXC.get(rc, RuntimeError)('msd_op_gemm_f32 failed (%d)' % rc)
+
+
+def op_attention(precision: str, q, k, v, o, heads: int, n_keys_valid: Optional[int] = None,
+                 stream: int = 0):
+  lib = load()
+  n_q, n_keys = q.shape[0], k.shape[0]
+  nv = n_keys if n_keys_valid is None else n_keys_valid
+  rc = lib.msd_op_attention(PRECISIONS[precision], _ptr(q), _ptr(k), _ptr(v), _ptr(o), n_q,
+                            n_keys, nv, heads, stream)
+  if rc:
+    raise _EXC.get(rc, RuntimeError)('msd_op_attention failed (%d)' % rc)

@@ -1,0 +1,121 @@
+"""Multi-GPU execution of the synthesis path: one process per GPU
+(``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU
+for the tests).  The DDPM loop itself needs NO collective:
+
+  * song-parallel replicas (primary): independent songs are dealt round-robin to
+    ranks (the reference shards songs with Beam, beam/evaluation.py:608-636);
+    for the no-context model every 5.12 s segment is independent too
+    (models/diffusion/models.py:167-199) so segments can be dealt the same way.
+  * chained hand-off: one song cut into ``world`` contiguous chunks; rank r
+    starts when rank r-1 delivers the mel of its last segment -- the previous
+    prediction that segment k+1 conditions on (beam/evaluation.py:194,209-210) --
+    as ONE point-to-point message float32 [1, C, n] (128 KiB): send/recv over a
+    single xGMI link, latency-bound.  Bit-identical to the sequential run, but
+    serial within a song: it pays only as a wavefront over >= world songs
+    (``chained_wavefront``).
+  * masked-boundary mode: chunk heads run with the context masked, i.e. the
+    reference's own ``--always_mask_context`` / ``i == 0`` behaviour at the cut
+    (beam/evaluation.py:66-68,195-198); true N-way speed-up of one song, NOT
+    identical to the sequential result at the world-1 boundaries.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def deal_round_robin(num_items: int, rank: int, world: int) -> List[int]:
+  """Indices of the items (songs / independent segments) owned by ``rank``."""
+  return list(range(rank, num_items, world))
+
+
+def contiguous_chunk(num_segments: int, rank: int, world: int) -> Tuple[int, int]:
+  """[start, stop) of the contiguous run of segments owned by ``rank``; earlier
+  ranks take the remainder so that chunk sizes differ by at most one."""
+  base, rem = divmod(num_segments, world)
+  start = rank * base + min(rank, rem)
+  return start, start + base + (1 if rank < rem else 0)
+
+
+def _dist():
+  import torch.distributed as dist
+  return dist
+
+
+def _as_comm_tensor(torch, array, device):
+  return torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32)).to(device)
+
+
+def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.ndarray],
+                    context_shape: Tuple[int, int, int], rank: int, world: int,
+                    comm_device='cpu', group=None, seed: int = 0, tag: int = 0) -> np.ndarray:
+  """Run this rank's contiguous chunk of ONE song with the context hand-off.
+
+  predict_sequence: ``InferenceModel.predict_sequence``-compatible callable
+    ``(tokens_list, seed=, init_context=, first_segment_index=) -> [1, T*k, n]``.
+  context_shape: (1, C, n) of the hand-off message.
+  Returns this rank's mel [1, T*k, n] (k = its number of segments, possibly 0 rows).
+  """
+  import torch
+  dist = _dist()
+  start, stop = contiguous_chunk(len(segments_tokens), rank, world)
+  init_context = None
+  if rank > 0 and 0 < start < len(segments_tokens):  # mirrors the sender's condition
+    buf = torch.empty(context_shape, dtype=torch.float32, device=comm_device)
+    dist.recv(buf, src=rank - 1, group=group, tag=tag)
+    init_context = buf.cpu().numpy()
+  mine = list(segments_tokens[start:stop])
+  n = context_shape[2]
+  if mine:
+    out = predict_sequence(mine, seed=seed, init_context=init_context, first_segment_index=start)
+    out = np.asarray(out, np.float32)
+  else:
+    out = np.zeros((1, 0, n), np.float32)
+  if rank + 1 < world and stop < len(segments_tokens):
+    c = context_shape[1]
+    if mine:
+      last = out[:, -c:, :]
+    else:  # empty chunk: forward what we received
+      last = init_context if init_context is not None else np.zeros(context_shape, np.float32)
+    dist.send(_as_comm_tensor(torch, last, comm_device), dst=rank + 1, group=group, tag=tag)
+  return out
+
+
+def masked_boundary_predict(predict_sequence: Callable, segments_tokens: Sequence[np.ndarray],
+                            rank: int, world: int, seed: int = 0) -> np.ndarray:
+  """This rank's chunk with the chunk head run context-masked (no communication)."""
+  start, stop = contiguous_chunk(len(segments_tokens), rank, world)
+  mine = list(segments_tokens[start:stop])
+  if not mine:
+    return np.zeros((1, 0, 0), np.float32)
+  return np.asarray(predict_sequence(mine, seed=seed, init_context=None,
+                                     first_segment_index=start), np.float32)
+
+
+def chained_wavefront(predict_sequence: Callable, songs: Sequence[Sequence[np.ndarray]],
+                      context_shape: Tuple[int, int, int], rank: int, world: int,
+                      comm_device='cpu', group=None, seed: int = 0) -> List[np.ndarray]:
+  """Every song chained over all ranks; rank r works on song j's chunk r while
+  rank r-1 already works on song j+1's chunk r-1 (a pipeline wavefront), so all
+  ranks are busy after ``world - 1`` fill steps.  Returns this rank's chunk of
+  every song, in song order."""
+  outs = []
+  for j, song in enumerate(songs):
+    outs.append(chained_predict(predict_sequence, song, context_shape, rank, world,
+                                comm_device=comm_device, group=group, seed=seed + j, tag=j))
+  return outs
+
+
+def gather_song(local_mel: np.ndarray, rank: int, world: int, group=None,
+                comm_device='cpu') -> Optional[np.ndarray]:
+  """Concatenate the per-rank chunks of one song on rank 0 (host-side; 15.5 MB for
+  a 10 min song -- not on the hot path).  Returns None on other ranks."""
+  import torch
+  dist = _dist()
+  objs = [None] * world if rank == 0 else None
+  dist.gather_object(np.asarray(local_mel, np.float32), objs, dst=0, group=group)
+  if rank != 0:
+    return None
+  parts = [o for o in objs if o is not None and o.shape[1] > 0]
+  return np.concatenate(parts, axis=1) if parts else np.zeros((1, 0, 0), np.float32)

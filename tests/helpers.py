@@ -1,0 +1,61 @@
+"""Shared test helpers: product spec -> oracle configs, seeded inputs."""
+import numpy as np
+
+import msd_amd
+from oracle import backend, fast, net, predict, sampler
+
+T5_FIELDS = ['vocab_size', 'emb_dim', 'num_heads', 'num_encoder_layers', 'num_decoder_layers',
+             'head_dim', 'mlp_dim', 'mlp_activations', 'max_decoder_noise_time',
+             'decoder_cross_attend_style', 'position_encoding', 'context_positions']
+
+
+def oracle_configs(spec):
+  t5 = net.T5Config(**{k: getattr(spec.t5, k) for k in T5_FIELDS})
+  d = spec.diffusion
+  dc = sampler.DiffusionConfig(
+      model_output=d.model_output,
+      classifier_free_guidance=sampler.ClassifierFreeGuidanceConfig(
+          eval_condition_weight=d.classifier_free_guidance.eval_condition_weight),
+      sampler=sampler.SamplerConfig(
+          name=d.sampler.name, clip_x0=d.sampler.clip_x0, logvar_type=d.sampler.logvar_type,
+          schedule=sampler.DiffusionSchedule(d.sampler.schedule.name,
+                                             num_steps=d.sampler.schedule.num_steps)))
+  return t5, dc
+
+
+def make_batch(spec, batch=1, seed=7, ctx_mask='ones', segment0=0):
+  """Model features with seeded content.  ctx_mask: 'ones' | 'zeros' | 'ragged'."""
+  rng = np.random.default_rng(seed)
+  toks = np.concatenate([msd_amd.synthetic.segment_tokens(spec, segment0 + b, min_len=8,
+                                                           max_len=spec.task_feature_lengths['inputs'] - 2)
+                         for b in range(batch)], 0)
+  out = {'encoder_input_tokens': toks}
+  n = 128
+  if spec.has_context:
+    c = spec.task_feature_lengths['targets_context']
+    out['encoder_continuous_inputs'] = rng.uniform(-13, 5, (batch, c, n)).astype(np.float32)
+    if ctx_mask == 'ones':
+      m = np.ones((batch, c), np.int32)
+    elif ctx_mask == 'zeros':
+      m = np.zeros((batch, c), np.int32)
+    else:  # a valid prefix of different length per row (exercises terminal_relative)
+      m = np.zeros((batch, c), np.int32)
+      for b in range(batch):
+        m[b, :int(rng.integers(1, c))] = 1
+    out['encoder_continuous_mask'] = m
+  out['decoder_target_tokens'] = np.zeros((batch, spec.task_feature_lengths['targets'], n), np.float32)
+  return out
+
+
+def make_noise(spec, batch=1, seed=11):
+  rng = np.random.default_rng(seed)
+  t, n = spec.task_feature_lengths['targets'], 128
+  steps = spec.diffusion.sampler.schedule.num_steps
+  return (rng.standard_normal((batch, t, n)).astype(np.float32),
+          rng.standard_normal((steps, batch, t, n)).astype(np.float32))
+
+
+def rms(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  return float(np.sqrt(np.mean((a - b) ** 2)))
