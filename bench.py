@@ -1,0 +1,249 @@
+"""Benchmark of the hot path: mel-frames/sec (+ xRTF) of 1000-step DDPM synthesis.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: ONE 256-frame (5.12 s)
+segment through ``InferenceModel.predict`` = encoders + cross-K/V cache + the full
+N-step DDPM loop (CFG weight 5 -> two decoder passes per step) + un-scaling, with
+the previous segment's prediction as context (segment-sequential,
+beam/evaluation.py:161-223).  Workload = BASELINE.json configs[2]:
+base_with_context, 1000-step DDPM, synthetic MIDI tokens, seeded synthetic
+weights.  The warm-up segments absorb the one-time restore/graph capture exactly
+like the reference excludes its first segment (beam/evaluation.py:217-220).
+
+N > 1: one process per GPU, every rank synthesizes its own song (song-parallel
+replicas, no collective on the data path: SURVEY.md 8(e)); value = frames of all
+ranks / max-over-ranks time ("weak" scaling).
+
+The JSON line also carries
+  roofline      dominant kernel class: algorithmic FLOP per launch / mean launch
+                duration measured with hipEvents on the launch stream
+                (msd_profile_steps), vs the dense bf16 MFMA peak;
+  cpu_baseline  the torch-CPU float32 oracle ("port") timed on a bounded sample
+                (encoders + a few DDPM steps, extrapolated linearly: per-step cost
+                is constant) on rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparse 5 PF)
+PEAK_HBM_GBS = 8000.0
+
+
+def class_flops(spec, s_valid: float, passes: int):
+  """Algorithmic FLOP per LAUNCH of each kernel class at batch 1:
+  2MNK per GEMM, 2*H*T*S*d each for QK^T and PV; elementwise work ignored;
+  bf16x3 counts the product once (it is one fp32-class GEMM)."""
+  t5 = spec.t5
+  d, h, f = t5.emb_dim, t5.num_heads, t5.mlp_dim
+  j = h * t5.head_dim
+  t = spec.task_feature_lengths['targets']
+  m = passes * t
+  return {
+      'gemm_qkv': 2.0 * m * 3 * j * d,
+      'attn_self': 4.0 * passes * h * t * t * t5.head_dim,
+      'gemm_attn_out': 2.0 * m * d * j,
+      'gemm_cross_q': 2.0 * t * j * d,
+      'attn_cross': 4.0 * h * t * s_valid * t5.head_dim,
+      'gemm_cross_out': 2.0 * t * d * j,
+      'gemm_mlp_in_geglu': 2.0 * m * 2 * f * d,
+      'gemm_mlp_out': 2.0 * m * d * f,
+      'final_proj_f32': 2.0 * m * 128 * d,
+      'in_proj_f32': 2.0 * t * 128 * d,
+  }
+
+
+def cpu_baseline(spec, params, batch, sample_steps: int):
+  """Oracle ('port') on the host cores: encoders once + `sample_steps` DDPM steps."""
+  import torch
+  from oracle import backend, fast
+  from tests import helpers
+  cores = os.cpu_count() or 1
+  xp = backend.TorchBackend('float32', threads=cores)
+  cfg, dc = helpers.oracle_configs(spec)
+  n_full = dc.sampler.schedule.num_steps
+  fm = fast.FastModel(xp, cfg, dc, params, spec.has_context)
+  t0 = time.perf_counter()
+  if spec.has_context:
+    fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'],
+              batch['encoder_continuous_mask'])
+  else:
+    fm.encode(batch['encoder_input_tokens'])
+  t_enc = time.perf_counter() - t0
+  t, n = spec.task_feature_lengths['targets'], 128
+  rng = np.random.default_rng(0)
+  z = xp.asarray(rng.standard_normal((1, t, n)).astype(np.float32))
+  w = dc.classifier_free_guidance.eval_condition_weight
+  fm.decoder_pass(z, n_full - 1, True)  # warm the weight caches
+  t0 = time.perf_counter()
+  for k in range(sample_steps):
+    i = n_full - 1 - k
+    e = fm.decoder_pass(z, i, True)
+    if w != 1:
+      e = w * e + (1 - w) * fm.decoder_pass(z, i, False)
+    z = z * 0.999 + 0.001 * e  # keep the data flowing; the sampler update is negligible
+  t_step = (time.perf_counter() - t0) / sample_steps
+  seg_s = t_enc + n_full * t_step
+  return {
+      'value': t / seg_s, 'unit': 'mel-frames/sec', 'cores': cores, 'kind': 'port',
+      'xRTF': (t * 320 / 16000.0) / seg_s,
+      'sample': 'torch-CPU float32 oracle (oracle/fast.py, cached cross K/V): encoders %.2fs + %d of %d '
+                'DDPM steps at %.3fs/step, extrapolated linearly to one %d-frame segment'
+                % (t_enc, sample_steps, n_full, t_step, t),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5, help='timed segments')
+  ap.add_argument('--warmup', type=int, default=1, help='untimed warm-up segments')
+  ap.add_argument('--preset', default='base_with_context')
+  ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+  ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
+  ap.add_argument('--cfg-weight', type=float, default=5.0)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-sample-steps', type=int, default=20)
+  ap.add_argument('--profile-steps', type=int, default=3)
+  args = ap.parse_args()
+
+  import torch
+  import msd_amd
+
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+  torch.cuda.set_device(local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+
+  spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
+  model = msd_amd.InferenceModel('synthetic:0', spec, precision=args.precision)
+  t_frames = spec.task_feature_lengths['targets']
+  n_seg = args.warmup + args.steps
+  # every rank plays its own synthetic song (different token streams per rank)
+  segs = [msd_amd.synthetic.segment_tokens(spec, 1000 * rank + k) for k in range(n_seg)]
+  c_len = model.targets_context_length
+  pred = None
+  if c_len is not None:
+    pred = torch.zeros((1, c_len, 128), dtype=torch.float32, device=model.device)
+
+  def run_segment(k):
+    nonlocal pred
+    batch = {'encoder_input_tokens': segs[k]}
+    if c_len is not None:
+      batch['encoder_continuous_inputs'] = pred
+      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((1, c_len), np.int32)
+    out, _ = model.predict(batch, seed=0, segment=k, return_torch=True)
+    if c_len is not None:
+      pred = out
+    return out
+
+  for k in range(args.warmup):
+    run_segment(k)
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  enc_s = smp_s = 0.0
+  for k in range(args.warmup, n_seg):
+    out = run_segment(k)
+    enc_s += model.last_timing['encode_s']
+    smp_s += model.last_timing['sample_s']
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  assert torch.isfinite(out).all(), 'non-finite mel output'
+  if dist is not None:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+  result = None
+  if rank == 0:
+    frames = world * args.steps * t_frames
+    value = frames / elapsed
+    audio_s = frames * 320 / 16000.0
+    passes = 2 if args.cfg_weight != 1.0 else 1
+    # ---- roofline of the dominant kernel (hipEvents on the launch stream) --------
+    nm = model._get_native()
+    toks = segs[-1]
+    s_valid = float((toks > 0).sum() + (c_len or 0))
+    with torch.cuda.device(model.device):
+      prof = nm.profile_steps(1, args.profile_steps, stream=model._stream.cuda_stream)
+    flops = class_flops(spec, s_valid, passes)
+    per_class = {}
+    for name, (ms, launches) in prof.items():
+      if launches:
+        per_class[name] = {'ms_per_launch': ms / launches, 'launches_per_step': launches / args.profile_steps,
+                           'ms_per_step': ms / args.profile_steps}
+    dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_step'])
+    achieved = flops[dom] / (per_class[dom]['ms_per_launch'] * 1e-3) / 1e12
+    step_flops = sum(flops[n] * per_class[n]['launches_per_step'] for n in per_class if n in flops)
+    roofline = {
+        'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS,
+        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 5), 'traffic': None,
+        'kernel_ms_per_launch': round(per_class[dom]['ms_per_launch'], 5),
+        'algorithmic_gflop_per_launch': round(flops[dom] / 1e9, 4),
+        'whole_step': {
+            'algorithmic_gflop': round(step_flops / 1e9, 2),
+            'eager_ms': round(sum(v['ms_per_step'] for v in per_class.values()), 4),
+            'graph_ms': round(smp_s / args.steps / args.num_steps * 1e3, 4),
+            'achieved_tflops_graph': round(step_flops / (smp_s / args.steps / args.num_steps) / 1e12, 3),
+        },
+        'per_class_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in per_class.items()},
+    }
+    result = {
+        'metric': 'mel-frames/sec', 'value': round(value, 3), 'unit': 'mel-frames/sec',
+        'xRTF': round(audio_s / elapsed, 4),
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/norm/softmax/sampler)'
+                 if args.precision == 'bf16x3' else 'bf16',
+        'data': 'synthetic (seeded tokens, reference-initialiser weights, Philox noise)',
+        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, batch 1, segment-sequential with context '
+                               'hand-off, %d segments of %d frames per GPU'
+                               % (args.preset, args.num_steps, args.cfg_weight, args.steps, t_frames),
+                   'precision': args.precision, 'parallelism': 'song-parallel x%d' % world},
+        'encode_ms_per_segment': round(enc_s / args.steps * 1e3, 3),
+        'sample_ms_per_segment': round(smp_s / args.steps * 1e3, 3),
+        'roofline': roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      batch = {'encoder_input_tokens': segs[-1]}
+      if c_len is not None:
+        batch['encoder_continuous_inputs'] = np.zeros((1, c_len, 128), np.float32)
+        batch['encoder_continuous_mask'] = np.ones((1, c_len), np.int32)
+      result['cpu_baseline'] = cpu_baseline(spec, model.params, batch, args.cpu_sample_steps)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps(result))
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,77 @@
+"""Generate the committed golden fixtures with the ORACLE (float64, torch-CPU).
+
+  python tests/golden/make_golden.py [tiny] [small] [base]
+
+JAX/T5X cannot be imported in this environment, so the goldens
+come from the oracle restatement -- pinned itself by the reference's
+layers_test.py known-answer tests (tests/test_oracle_kat.py) and by the
+faithful-vs-fast equivalence tests -- not from the reference binary.  Every
+input is regenerated from seeds by the tests (weights: synthetic.init_params(spec,
+seed); tokens: synthetic.segment_tokens; noise: oracle/philox.py), so a fixture
+holds only the expected mel output and the seeds.
+
+  tiny_context_n6.npz        tiny_context preset, 6 steps, batch 2, ragged context
+  small_n1000.npz            BASELINE config 2 shape: small/no-context, 1000 steps, 1 segment
+  base_with_context_n1000.npz  BASELINE config 3 shape: 2 chained segments, 1000 steps
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import msd_amd  # noqa: E402
+from oracle import backend, fast, philox  # noqa: E402
+from tests import helpers  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tiny():
+  spec = msd_amd.config.preset('tiny_context', num_steps=6)
+  params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
+  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend('float64')
+  out = xp.to_numpy(fast.FastModel(xp, cfg, dc, params, True).predict(batch, init_z, noise)[0])
+  np.savez_compressed(os.path.join(HERE, 'tiny_context_n6.npz'), mel=out.astype(np.float32),
+                      weight_seed=3, jitter=0.1, batch_seed=7, noise_seed=11)
+
+
+def song(preset, n_segments, name, weight_seed=0, seed=0):
+  spec = msd_amd.config.preset(preset, num_steps=1000)
+  params = msd_amd.synthetic.init_params(spec, weight_seed)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend('float64', threads=os.cpu_count())
+  fm = fast.FastModel(xp, cfg, dc, params, spec.has_context)
+  t, n = spec.task_feature_lengths['targets'], 128
+  c = spec.task_feature_lengths.get('targets_context')
+  pred = np.zeros((1, c or 0, n), np.float32)
+  outs = []
+  for k in range(n_segments):
+    t0 = time.time()
+    batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, k)}
+    if spec.has_context:
+      batch['encoder_continuous_inputs'] = pred
+      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((1, c), np.int32)
+    init_z, noise = philox.segment_noise((1, t, n), 1000, seed=seed, segment=k)
+    out = xp.to_numpy(fm.predict(batch, init_z, noise)[0]).astype(np.float32)
+    pred = out
+    outs.append(out)
+    print('%s segment %d: %.0fs' % (name, k, time.time() - t0), flush=True)
+  np.savez_compressed(os.path.join(HERE, name), mel=np.concatenate(outs, 1), weight_seed=weight_seed,
+                      noise_seed=seed, n_segments=n_segments)
+
+
+if __name__ == '__main__':
+  what = sys.argv[1:] or ['tiny']
+  if 'tiny' in what:
+    tiny()
+  if 'small' in what:
+    song('small', 1, 'small_n1000.npz')
+  if 'base' in what:
+    song('base_with_context', 2, 'base_with_context_n1000.npz')

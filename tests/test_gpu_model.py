@@ -1,0 +1,236 @@
+"""-m gpu: the whole path through the C-ABI (encode, tables, one decoder pass,
+the sampler loop, predict, predict_sequence) against the oracle on seeded inputs.
+
+Tolerances.  Integer/byte data (schedule indices, masks) are exact.  Floating
+point follows BASELINE.json's bar -- mel frames within 1e-3 rms -- read this way:
+the DDPM chain with few huge steps amplifies rounding (float32 itself is ~1e-2
+from float64 on the 6-step tiny config), so short runs compare the device error
+against the float32-oracle error as yardstick (fp32-class: <= 3x + 1e-4); the
+1000-step runs (test_gpu_full.py) use the absolute 1e-3 rms bar."""
+import numpy as np
+import pytest
+
+import msd_amd
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(spec, params, batch, init_z, noise, dtype='float64', precision='f32', trace=None):
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend(dtype)
+  fm = fast.FastModel(xp, cfg, dc, params, spec.has_context, precision=precision)
+  out = fm.predict(batch, init_z, noise, trace=trace)[0]
+  return xp.to_numpy(out).astype(np.float64), fm
+
+
+@pytest.fixture(scope='module')
+def tiny_ctx():
+  import torch
+  assert torch.cuda.is_available()
+  spec = msd_amd.config.preset('tiny_context', num_steps=6)
+  params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
+  model = msd_amd.InferenceModel(params, spec, batch_size=2)
+  return spec, params, model
+
+
+def test_schedule_table_matches_oracle(tiny_ctx):
+  spec, params, model = tiny_ctx
+  from oracle import backend, sampler
+  sched = model._get_native().schedule()
+  n = spec.diffusion.sampler.schedule.num_steps
+  xp = backend.NumpyBackend('float32')
+  i = np.arange(n, dtype=np.float32)
+  cos = sampler.DiffusionSchedule('cosine', num_steps=n)
+  lt = sampler.get_logsnr_t(xp, (i + 1) / np.float32(n), cos)
+  ls = sampler.get_logsnr_t(xp, i / np.float32(n), cos)
+  np.testing.assert_allclose(sched[:, 0], lt, atol=3e-5)
+  np.testing.assert_allclose(sched[:, 1], ls, atol=3e-5)
+  rev = sampler.diffusion_reverse(backend.NumpyBackend('float64'), x0=np.ones(n), z_t=np.zeros(n),
+                                  logsnr_s=ls.astype(np.float64), logsnr_t=lt.astype(np.float64),
+                                  logvar_type='large')
+  np.testing.assert_allclose(sched[:, 5], rev['mean'], rtol=2e-4, atol=1e-7)   # (1-r) alpha_s
+  np.testing.assert_allclose(sched[:, 6], rev['std'], rtol=2e-4, atol=1e-7)
+
+
+def test_film_table_matches_oracle(tiny_ctx):
+  """FiLM scale/bias table = sinusoid(t*2e4) -> Dense -> swish -> Dense -> swish -> Dense, all fp32
+  (network.py:377-392, layers.py:660-665).  The float32 time signal is intrinsically
+  implementation-sensitive: scaled_time reaches 2e4 rad, so one ulp of exp() in
+  inv_timescales moves sin/cos by ~1e-3 in the highest-frequency channels (true of the
+  reference across XLA backends as well) -- hence the looser bound on this table."""
+  spec, params, model = tiny_ctx
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  n, ld, d = dc.sampler.schedule.num_steps, cfg.num_decoder_layers, cfg.emb_dim
+  film = model._get_native().debug_read('film').reshape(n, 2 * ld, 2 * d)
+  for dt, tol in (('float32', 2e-3), ('float64', 5e-3)):
+    fm = fast.FastModel(backend.NumpyBackend(dt), cfg, dc, params, True)
+    worst = max(float(np.abs(film[:, 2 * l + k] - fm.film[l][k]).max())
+                for l in range(ld) for k in range(2))
+    print('film table max abs diff vs %s oracle: %.3e' % (dt, worst))
+    assert worst < tol
+
+
+@pytest.mark.parametrize('mask', ['ones', 'zeros', 'ragged'])
+def test_encode_and_single_decoder_pass(tiny_ctx, mask):
+  import torch
+  spec, params, model = tiny_ctx
+  nm = model._get_native()
+  batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)
+  ref_out, fm = None, None
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.NumpyBackend('float64')
+  fm = fast.FastModel(xp, cfg, dc, params, True)
+  fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'],
+            batch['encoder_continuous_mask'])
+  ctx = torch.as_tensor(batch['encoder_continuous_inputs']).cuda()
+  nm.encode(2, batch['encoder_input_tokens'], ctx, batch['encoder_continuous_mask'])
+  z = np.random.default_rng(0).standard_normal((2, 64, 128)).astype(np.float32)
+  zd = torch.as_tensor(z).cuda()
+  for step, cond in [(5, True), (2, True), (0, False), (3, False)]:
+    eps = torch.zeros_like(zd)
+    nm.decoder_pass(2, step, zd, cond, eps)
+    torch.cuda.synchronize()
+    want = fm.decoder_pass(z.astype(np.float64), step, cond)
+    err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 2e-4, (mask, step, cond, err)  # fp32-class (bf16 operands would give ~1e-2)
+
+
+def test_predict_explicit_noise_matches_oracle(tiny_ctx):
+  spec, params, model = tiny_ctx
+  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  got, scores = model.predict(batch, init_z=init_z, noise=noise)
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  e_dev, e_f32 = helpers.rms(got, ref64), helpers.rms(ref32, ref64)
+  print('rms vs float64: device %.3e float32-oracle %.3e' % (e_dev, e_f32))
+  assert got.dtype == np.float32 and got.shape == (2, 64, 128)
+  assert scores.shape == (2,) and not scores.any()
+  assert e_dev <= 3 * e_f32 + 1e-4
+
+
+def test_predict_seed_uses_documented_philox(tiny_ctx):
+  spec, params, model = tiny_ctx
+  from oracle import philox
+  batch = helpers.make_batch(spec, batch=1)
+  got, _ = model.predict(batch, seed=42, segment=3)
+  init_z, noise = philox.segment_noise((1, 64, 128), 6, seed=42, segment=3)
+  again, _ = model.predict(batch, init_z=init_z, noise=noise)
+  # same bits in, ulp-level differences only from device vs NumPy log/sin/cos
+  assert helpers.rms(got, again) < 5e-2
+  same, _ = model.predict(batch, seed=42, segment=3)
+  np.testing.assert_array_equal(got, same)                       # deterministic
+  other, _ = model.predict(batch, seed=43, segment=3)
+  assert helpers.rms(got, other) > 0.1
+
+
+def test_cfg_weight_one_and_ddim_and_no_context_model():
+  import torch
+  for preset, kw in [('tiny_context', dict(cfg_weight=1.0)), ('tiny', dict(cfg_weight=5.0))]:
+    spec = msd_amd.config.preset(preset, num_steps=5, **kw)
+    params = msd_amd.synthetic.init_params(spec, 9, norm_scale_jitter=0.1)
+    model = msd_amd.InferenceModel(params, spec)
+    batch = helpers.make_batch(spec)
+    init_z, noise = helpers.make_noise(spec)
+    got, _ = model.predict(batch, init_z=init_z, noise=noise)
+    ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+    ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+    assert helpers.rms(got, ref64) <= 3 * helpers.rms(ref32, ref64) + 1e-4, preset
+  # DDIM switch (diffusion_utils.py:369-379)
+  import dataclasses
+  spec = msd_amd.config.preset('tiny_context', num_steps=5)
+  d = spec.diffusion
+  spec = dataclasses.replace(spec, diffusion=dataclasses.replace(
+      d, sampler=dataclasses.replace(d.sampler, name='ddim')))
+  params = msd_amd.synthetic.init_params(spec, 9)
+  model = msd_amd.InferenceModel(params, spec)
+  batch = helpers.make_batch(spec)
+  init_z, _ = helpers.make_noise(spec)
+  got, _ = model.predict(batch, init_z=init_z)
+  ref64, _ = _oracle(spec, params, batch, init_z, None, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, None, 'float32')
+  assert helpers.rms(got, ref64) <= 3 * helpers.rms(ref32, ref64) + 1e-4
+
+
+def test_bf16_mode_is_close_to_its_emulation(tiny_ctx):
+  """The fast non-parity mode: checked against the oracle's bf16 emulation on one
+  decoder pass (a full chain in bf16 is chaotic by design of the test config)."""
+  import torch
+  spec, params, _ = tiny_ctx
+  model = msd_amd.InferenceModel(params, spec, precision='bf16')
+  nm = model._get_native()
+  batch = helpers.make_batch(spec)
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend('float32')
+  fm = fast.FastModel(xp, cfg, dc, params, True, precision='bf16')
+  fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'],
+            batch['encoder_continuous_mask'])
+  nm.encode(1, batch['encoder_input_tokens'], torch.as_tensor(batch['encoder_continuous_inputs']).cuda(),
+            batch['encoder_continuous_mask'])
+  z = np.random.default_rng(0).standard_normal((1, 64, 128)).astype(np.float32)
+  eps = torch.zeros((1, 64, 128), device='cuda')
+  nm.decoder_pass(1, 3, torch.as_tensor(z).cuda(), True, eps)
+  torch.cuda.synchronize()
+  want = xp.to_numpy(fm.decoder_pass(xp.asarray(z), 3, True))
+  assert np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max() < 3e-2
+
+
+def test_predict_sequence_matches_oracle_song(tiny_ctx):
+  spec, params, model = tiny_ctx
+  from oracle import backend, philox, predict
+  cfg, dc = helpers.oracle_configs(spec)
+  segs = [msd_amd.synthetic.segment_tokens(spec, k, min_len=8, max_len=100) for k in range(3)]
+  got = model.predict_sequence(segs, seed=5)
+  assert got.shape == (1, 192, 128)
+  zs, ns = zip(*[philox.segment_noise((1, 64, 128), 6, seed=5, segment=k) for k in range(3)])
+  outs = {}
+  for dt in ('float64', 'float32'):
+    xp = backend.TorchBackend(dt)
+    outs[dt] = predict.predict_song(xp, cfg, dc, params, segs, zs, ns, context_length=64)
+  e_dev, e_f32 = helpers.rms(got, outs['float64']), helpers.rms(outs['float32'], outs['float64'])
+  print('song rms vs float64: device %.3e float32-oracle %.3e' % (e_dev, e_f32))
+  assert e_dev <= 3 * e_f32 + 5e-2  # + philox transcendental ulps through 3 chained segments
+  masked = model.predict_sequence(segs, seed=5, always_mask_context=True)
+  np.testing.assert_array_equal(masked[:, :64], got[:, :64])   # segment 0 identical
+  assert helpers.rms(masked[:, 64:], got[:, 64:]) > 1e-3        # context matters afterwards
+
+
+def test_error_paths(tiny_ctx):
+  spec, params, model = tiny_ctx
+  nm = model._get_native()
+  batch = helpers.make_batch(spec)
+  bad = dict(batch)
+  bad['encoder_input_tokens'] = batch['encoder_input_tokens'][:, :5]
+  with pytest.raises(ValueError):
+    model.predict(bad)
+  bad = dict(batch)
+  bad['encoder_input_tokens'] = batch['encoder_input_tokens'] + 100000
+  with pytest.raises(ValueError):
+    model.predict(bad)
+  with pytest.raises(KeyError):
+    nm.set_weight('decoder/not_a_weight', np.zeros(3, np.float32))
+  with pytest.raises(ValueError):
+    nm.set_weight('decoder/decoder_norm/scale', np.zeros(7, np.float32))
+  fresh = msd_amd.native.NativeModel(msd_amd.inference._to_native_config(
+      spec, model.audio_codec, 1, 'bf16x3'))
+  with pytest.raises(RuntimeError):
+    fresh.encode(1, batch['encoder_input_tokens'])
+
+
+def test_empty_inputs_give_unconditional_result(tiny_ctx):
+  """All-PAD tokens + masked context: no key anywhere -> cross-attention is exactly
+  zero for the conditional pass too (layers.py:882-902), so CFG collapses."""
+  spec, params, model = tiny_ctx
+  batch = helpers.make_batch(spec, ctx_mask='zeros')
+  batch['encoder_input_tokens'] = np.zeros_like(batch['encoder_input_tokens'])
+  init_z, noise = helpers.make_noise(spec)
+  got, _ = model.predict(batch, init_z=init_z, noise=noise)
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  assert np.isfinite(got).all()
+  assert helpers.rms(got, ref64) <= 3 * helpers.rms(ref32, ref64) + 1e-4

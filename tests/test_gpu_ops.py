@@ -1,0 +1,109 @@
+"""-m gpu: the HIP building blocks through the C-ABI against NumPy/oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+  import torch
+  import msd_amd
+  assert torch.cuda.is_available(), 'these tests need the MI355X'
+  msd_amd.native.load()
+  return torch, msd_amd.native
+
+
+def _dev(torch, a):
+  return torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16', 2e-2), ('bf16x3', 2e-5)])
+@pytest.mark.parametrize('m,n,k', [(64, 64, 64), (256, 768, 768), (512, 128, 2048), (192, 320, 128)])
+def test_gemm_bf16(env, prec, tol, m, n, k):
+  torch, native = env
+  rng = np.random.default_rng(m + n + k)
+  a = rng.standard_normal((m, k)).astype(np.float32)   # asymmetric, transpose-detecting
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
+  native.op_gemm_bf16(prec, _dev(torch, a), _dev(torch, w), c)
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  err = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
+  assert err < tol, err
+
+
+def test_gemm_bf16_identity_detects_transposes(env):
+  torch, native = env
+  k = 128
+  a = np.eye(k, dtype=np.float32)[:64] * 1.0
+  w = (np.arange(k * 192).reshape(k, 192) % 251).astype(np.float32)  # exactly representable in bf16
+  c = torch.zeros((64, 192), dtype=torch.float32, device='cuda')
+  native.op_gemm_bf16('bf16', _dev(torch, a), _dev(torch, w), c)
+  np.testing.assert_array_equal(c.cpu().numpy(), w[:64])
+
+
+@pytest.mark.parametrize('m,n,k', [(64, 64, 16), (1000, 128, 768), (256, 768, 128), (7, 64, 32)])
+def test_gemm_f32(env, m, n, k):
+  torch, native = env
+  rng = np.random.default_rng(m * n + k)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = rng.standard_normal((k, n)).astype(np.float32)
+  c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
+  native.op_gemm_f32(_dev(torch, a), _dev(torch, w), c)
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16', 3e-2), ('bf16x3', 3e-5)])
+@pytest.mark.parametrize('nq,nk,valid,heads', [(32, 32, 32, 1), (256, 256, 256, 2), (64, 2304, 2304, 3),
+                                               (64, 512, 301, 2), (32, 64, 1, 1), (32, 64, 0, 2)])
+def test_attention(env, prec, tol, nq, nk, valid, heads):
+  """Unscaled softmax(q k^T) v with a key-count bound (== the reference's -1e10
+  padding bias, layers.py:341-346) and the all-masked -> 0 rule (layers.py:882-902)."""
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(nq + nk + valid)
+  j = heads * 64
+  q = (rng.standard_normal((nq, j)) * 0.35).astype(np.float32)
+  k = (rng.standard_normal((nk, j)) * 0.35).astype(np.float32)
+  v = rng.standard_normal((nk, j)).astype(np.float32)
+  o = torch.zeros((nq, j), dtype=torch.float32, device='cuda')
+  native.op_attention(prec, _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads, n_keys_valid=valid)
+  got = o.cpu().numpy()
+  if valid == 0:
+    np.testing.assert_array_equal(got, 0.0)
+    return
+  xp = backend.NumpyBackend('float64')
+  sh = lambda x, n: x.reshape(1, n, heads, 64).astype(np.float64)
+  ref = ops.dot_product_attention(xp, sh(q, nq), sh(k[:valid], valid), sh(v[:valid], valid))
+  ref = ref.reshape(nq, j)
+  assert np.abs(got - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+def test_attention_spiked_key_forces_online_rescale(env):
+  """A key block whose max jumps by ~60 forces the running-max rescale path."""
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(5)
+  nq, nk, heads = 32, 256, 1
+  q = (rng.standard_normal((nq, 64)) * 0.3).astype(np.float32)
+  k = (rng.standard_normal((nk, 64)) * 0.3).astype(np.float32)
+  v = rng.standard_normal((nk, 64)).astype(np.float32)
+  k[200] = q[3] * 40.0  # q[3].k[200] >> every other score, in the 7th key block
+  o = torch.zeros((nq, 64), dtype=torch.float32, device='cuda')
+  native.op_attention('bf16x3', _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads)
+  xp = backend.NumpyBackend('float64')
+  sh = lambda x, n: x.reshape(1, n, 1, 64).astype(np.float64)
+  ref = ops.dot_product_attention(xp, sh(q, nq), sh(k, nk), sh(v, nk)).reshape(nq, 64)
+  assert np.abs(o.cpu().numpy() - ref).max() < 1e-4
+
+
+def test_philox_normal_matches_oracle(env):
+  torch, native = env
+  from oracle import philox
+  for n, seed, stream, sub in [(4096, 0, 0, 0), (1001, 123456789012345, 7, 3), (32768, 1, 2 ** 33 + 5, 1000)]:
+    out = torch.empty(n, dtype=torch.float32, device='cuda')
+    native.fill_normal(out, seed, stream, sub)
+    ref = philox.normal(n, seed, stream, sub)
+    # identical counters/bits; the float32 log/sin/cos of device and NumPy differ by ulps
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)
