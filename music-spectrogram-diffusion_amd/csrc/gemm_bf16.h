@@ -6,18 +6,21 @@
 // product is Ah.Wh + Ah.Wl + Al.Wh (three v_mfma_f32_16x16x32_bf16 per tile),
 // fp32 accumulate: fp32-class accuracy at the bf16 MFMA rate / 3.
 //
-// Regime: M is 256-512, so a launch has few output tiles and each tile's K loop is
-// a serial chain of memory latencies.  Structure chosen for that regime:
-//   * block = 4 waves that ALL own the same BM x BN output tile and split K between
-//     them (wave w takes the 32-wide K-steps w, w+4, ...): 4x shorter dependent
-//     chains, and no operand byte is fetched twice inside a block;
-//   * both operands are K-contiguous, so A and W^T fragments are plain 16-byte
-//     global loads (lane: row l&15, k-chunk l>>4) straight into the MFMA operand
-//     registers through a DEPTH-deep, statically indexed register ring -- no LDS,
-//     no barrier and no s_waitcnt vmcnt(0) inside the K loop;
-//   * the four partial tiles are summed through LDS (two rounds, 2 slabs) and the
-//     epilogue runs on the summed tile with a row-of-8 (or column-of-8) item per
-//     thread, i.e. fully coalesced 16/32-byte stores whatever the MFMA layout was.
+// What bounds this kernel on MI355X (profiles/r01_*): with M = 256..512 every
+// operand is L2-resident or streamed once, and the limiter is the per-CU vector
+// memory path (TA): tools/ubench/load_patterns.hip measures 17 B/clk/CU for
+// MFMA-fragment-shaped loads (16 rows x 64 B per instruction) but 43 B/clk/CU for
+// full 128-byte lines.  Hence:
+//   * operands enter the CU ONCE per block, as full 128 B rows (BK = 64 bf16,
+//     8 lanes x 16 B per row, 8 rows per wave-instruction), and are shared by the
+//     2x2 waves through LDS; bigger block tiles (BM = 128) for the wide-N GEMMs cut
+//     bytes per FLOP further;
+//   * global -> register ring (R tiles in flight) -> XOR-swizzled LDS (double
+//     buffered) -> ds_read_b128 fragments; the ring is statically indexed and the
+//     steady-state loop is branch-free with pinned issue order, so hipcc emits exact
+//     counted s_waitcnt vmcnt(N) and never drains the younger prefetches;
+//   * one barrier per K-tile; the accumulators go through an LDS slab so that the
+//     epilogue stores whole 16/32-byte row segments whatever the MFMA layout was.
 // blockIdx -> tile is XCD-aware (block b runs on XCD b % 8): the BM-blocks of one
 // column slice are consecutive on ONE XCD, so a weight slice is fetched from HBM
 // once into that XCD's L2.
@@ -34,6 +37,8 @@ struct GemmParams {
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+// native vector (NOT HIP's uint4 struct): arrays of it stay in registers under SROA
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ mfma_bf16x8 as_frag(uint4 v) {
   union { uint4 u; mfma_bf16x8 f; } c;
@@ -50,158 +55,348 @@ __device__ __forceinline__ mfma_bf16x8 ld_frag16(const bf16_t* p) {
 // V^T loads: offset o -> 8*((o>>2)&1) + (o&3) + 4*(o>>3)   (see attention.h)
 __device__ __forceinline__ int vt_perm16(int o) { return 8 * ((o >> 2) & 1) + (o & 3) + 4 * (o >> 3); }
 
+#ifndef MSD_ABL
+#define MSD_ABL 0  // ablation switch for tools/ubench/gemm_bench.hip; 0 = the product kernel
+#endif
+
 constexpr int kSlabPad = 4;
+constexpr int kGemmBK = 64;  // bf16 elements per K-tile = one 128-byte line per row
 
-template <int NP, int BM, int BN, int DEPTH, bool PIN, class Epi>
+// byte offset of 16-byte chunk `chunk` (0..7) of `row` in a [rows][64] bf16 LDS tile;
+// chunk ^ (row & 7) makes every ds_read_b128 lane group (16 rows x one chunk) and every
+// ds_write_b128 group (8 lanes of one row) bank-conflict free.
+__device__ __forceinline__ int lds_tile_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ (row & 7)) << 4);
+}
+
+template <int NP, int BM, int BN, int R, class Epi>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
-  constexpr int FM = BM / 16, FN = BN / 16;
+  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile (2 x 2 waves)
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = NP * (A_BYTES + B_BYTES);
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-byte loads per thread per plane
   constexpr int LDS_LD = BN + kSlabPad;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* slab = reinterpret_cast<float*>(smem_raw);  // [2][BM][LDS_LD]
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must be a multiple of 32");
+  static_assert(BM * LDS_LD * 4 <= 2 * STAGE_BYTES, "epilogue slab must fit the operand LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
 
   // ---- XCD-aware tile mapping -------------------------------------------------
   const int nbm = p.M / BM, nbn = p.N / BN;
   int bm, bn;
   {
-    const int b = blockIdx.x, nblk = nbm * nbn;
+    const int b = blockIdx.x;
     if ((nbn & 7) == 0) {
-      const int xcd = b & 7, t = b >> 3;   // t-th block of this XCD
+      const int xcd = b & 7, t = b >> 3;  // t-th block of this XCD
       bm = t % nbm;
       bn = (t / nbm) * 8 + xcd;
     } else {
       bm = b % nbm;
       bn = b / nbm;
     }
-    (void)nblk;
   }
   const int m0 = bm * BM, n0 = bn * BN;
 
-  // ---- K loop: this wave's steps are wave, wave+4, ... -------------------------
-  const int nsteps = p.K / 32;
-  const int cnt = (nsteps - wave + 3) >> 2;
-  const bf16_t* ap[NP];
-  const bf16_t* bp[NP];
+  // global source of this thread: rows (tid>>3) + 32*i, 16-byte chunk tid&7
+  const int ld_row = tid >> 3, ld_chunk = tid & 7;
+  const bf16_t* ga[NP];
+  const bf16_t* gb[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
-    ap[pl] = p.A[pl] + (size_t)(m0 + (lane & 15)) * p.lda + (lane >> 4) * 8 + wave * 32;
-    bp[pl] = p.B[pl] + (size_t)(n0 + (lane & 15)) * p.ldb + (lane >> 4) * 8 + wave * 32;
+    ga[pl] = p.A[pl] + (size_t)(m0 + ld_row) * p.lda + ld_chunk * 8;
+    gb[pl] = p.B[pl] + (size_t)(n0 + ld_row) * p.ldb + ld_chunk * 8;
   }
-  const size_t a_frag_stride = (size_t)16 * p.lda, b_frag_stride = (size_t)16 * p.ldb;
+  const size_t a_step = (size_t)32 * p.lda, b_step = (size_t)32 * p.ldb;
 
-  mfma_bf16x8 ra[DEPTH][NP][FM], rb[DEPTH][NP][FN];
+  u32x4 ra[R][NP][A_LD], rb[R][NP][B_LD];
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define MSD_GEMM_LOAD(STAGE, STEP)                                                        \
-  {                                                                                       \
-    const int koff_ = (STEP) * 128; /* 4 waves x 32 elements per round */                 \
-    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                   \
-      _Pragma("unroll") for (int i = 0; i < FM; ++i)                                      \
-          ra[STAGE][pl][i] = ld_frag16(ap[pl] + i * a_frag_stride + koff_);               \
-      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                      \
-          rb[STAGE][pl][j] = ld_frag16(bp[pl] + j * b_frag_stride + koff_);               \
-    }                                                                                     \
+#define MSD_G_LOAD(S, KT)                                                                  \
+  if (MSD_ABL != 1 || (KT) <= R) {                                                         \
+    const int k0_ = (KT) * kGemmBK;                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                    \
+      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                     \
+          ra[S][pl][i] = *reinterpret_cast<const u32x4*>(ga[pl] + i * a_step + k0_);       \
+      _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                     \
+          rb[S][pl][i] = *reinterpret_cast<const u32x4*>(gb[pl] + i * b_step + k0_);       \
+    }                                                                                      \
+  }
+#define MSD_G_STORE(S, BUF)                                                                \
+  if (MSD_ABL != 4) {                                                                      \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                              \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                    \
+      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                     \
+          *reinterpret_cast<u32x4*>(base_ + pl * A_BYTES + lds_tile_off(ld_row + 32 * i, ld_chunk)) = ra[S][pl][i]; \
+      _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                     \
+          *reinterpret_cast<u32x4*>(base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(ld_row + 32 * i, ld_chunk)) = rb[S][pl][i]; \
+    }                                                                                      \
   }
   // D[n][m] orientation (first operand = W^T fragment): lane holds C[m = l&15][n = (l>>4)*4 + r]
-#define MSD_GEMM_COMPUTE(STAGE)                                                           \
-  {                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                        \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                      \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[STAGE][0][j], ra[STAGE][0][i], acc[i][j], 0, 0, 0); \
-      if (NP == 2) {                                                                      \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[STAGE][NP - 1][j], ra[STAGE][0][i], acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[STAGE][0][j], ra[STAGE][NP - 1][i], acc[i][j], 0, 0, 0); \
-      }                                                                                   \
-    }                                                                                     \
+#define MSD_G_COMPUTE(BUF)                                                                 \
+  {                                                                                        \
+    const char* base_ = smem + (BUF) * STAGE_BYTES;                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
+      mfma_bf16x8 fa[NP][FM], fb[NP][FN];                                                  \
+      const int c_ = kk * 4 + (lane >> 4);                                                 \
+      if (MSD_ABL != 3 || kt == 0)                                                         \
+      _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                  \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                     \
+            fa[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(                             \
+                base_ + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c_));  \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+            fb[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(                             \
+                base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c_)); \
+      }                                                                                    \
+      if (MSD_ABL == 2) {                                                                  \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < FN; ++j) \
+          _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                              \
+            asm volatile("" ::"v"(fa[pl][i]), "v"(fb[pl][j]));                             \
+          }                                                                                \
+      } else                                                                               \
+      _Pragma("unroll") for (int i = 0; i < FM; ++i)                                       \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0); \
+        if (NP == 2) {                                                                     \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NP - 1][j], fa[0][i], acc[i][j], 0, 0, 0); \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[NP - 1][i], acc[i][j], 0, 0, 0); \
+        }                                                                                  \
+      }                                                                                    \
+    }                                                                                      \
   }
+#define MSD_PIN() __builtin_amdgcn_sched_barrier(0)
 
-  int it = 0;
-  if (cnt >= 2 * DEPTH) {
-    // steady state: the ring is filled and every stage is computed and refilled
-    // UNCONDITIONALLY, so hipcc can emit exact counted s_waitcnt vmcnt(N); any
-    // conditional load on the way into this loop makes its waitcnt pass assume the
-    // shortest path and drain the younger prefetches at every round.
+  // Tile kt lives in LDS buffer kt & 1; register stage kt % R holds tile kt while in
+  // flight.  Invariant at the top of iteration kt: LDS[kt&1] = tile kt (visible to
+  // all waves), register stages hold tiles kt+1 .. kt+R (loads issued, maybe in flight).
+  const int nk = p.K / kGemmBK;
+  int kt = 0;
+  if (nk > 2 * R) {
+    // prologue: tile 0 through registers into LDS, then fill the ring with tiles 1..R
+    MSD_G_LOAD(0, 0)
+    MSD_PIN();
+    MSD_G_STORE(0, 0)
+    MSD_PIN();
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      MSD_GEMM_LOAD(d, d)
-      // the ring must be filled in stage order too: the loop-header wait is the merge
-      // of this path and the back edge
-      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < R; ++s) {
+      MSD_G_LOAD(((s + 1) % R), s + 1)
+      MSD_PIN();
     }
-    for (; it + 2 * DEPTH <= cnt; it += DEPTH) {
+    __syncthreads();
+    // steady state, unrolled by 2R so that ring stage AND LDS buffer are compile-time
+    for (; kt + 2 * R + R < nk; kt += 2 * R) {
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        MSD_GEMM_COMPUTE(d)
-        if (PIN) __builtin_amdgcn_sched_barrier(0);  // keep stage d's MFMAs ahead of its refill
-        MSD_GEMM_LOAD(d, it + d + DEPTH)
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < 2 * R; ++u) {
+        // tile kt+u is in LDS[(u)&1] (kt is a multiple of 2R, hence even); tile kt+u+1 is
+        // in ring stage (u+1)%R: move it to the other LDS buffer, refill the stage
+        MSD_G_STORE(((u + 1) % R), ((u + 1) & 1))
+        MSD_PIN();
+        MSD_G_LOAD(((u + 1) % R), kt + u + 1 + R)
+        MSD_PIN();
+        MSD_G_COMPUTE((u & 1))
+        MSD_PIN();
+        __syncthreads();
+      }
+    }
+    // drain with conditional refills
+    for (; kt < nk; kt += 2 * R) {
+#pragma unroll
+      for (int u = 0; u < 2 * R; ++u) {
+        if (kt + u < nk) {
+          if (kt + u + 1 < nk) MSD_G_STORE(((u + 1) % R), ((u + 1) & 1))
+          if (kt + u + 1 + R < nk) MSD_G_LOAD(((u + 1) % R), kt + u + 1 + R)
+          MSD_G_COMPUTE((u & 1))
+          __syncthreads();
+        }
       }
     }
   } else {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-      if (d < cnt) MSD_GEMM_LOAD(d, d)
-  }
-  // drain: at most 2*DEPTH - 1 steps left
-  for (; it < cnt; it += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      if (it + d < cnt) {
-        MSD_GEMM_COMPUTE(d)
-        if (it + d + DEPTH < cnt) MSD_GEMM_LOAD(d, it + d + DEPTH)
+    // short K: plain double-buffered loop through ring stage 0
+    MSD_G_LOAD(0, 0)
+    MSD_G_STORE(0, 0)
+    __syncthreads();
+    for (; kt < nk; ++kt) {
+      if (kt + 1 < nk) MSD_G_LOAD(0, kt + 1)
+      if (kt & 1) { MSD_G_COMPUTE(1) } else { MSD_G_COMPUTE(0) }
+      if (kt + 1 < nk) {
+        if (kt & 1) { MSD_G_STORE(0, 0) } else { MSD_G_STORE(0, 1) }
       }
+      __syncthreads();
     }
   }
-#undef MSD_GEMM_LOAD
-#undef MSD_GEMM_COMPUTE
+#undef MSD_G_LOAD
+#undef MSD_G_STORE
+#undef MSD_G_COMPUTE
+#undef MSD_PIN
 
-  // ---- cross-wave reduction (2 rounds through 2 LDS slabs) -----------------------
-  auto slab_at = [&](int s, int m, int n) -> float* { return slab + ((size_t)s * BM + m) * LDS_LD + n; };
+  // ---- accumulators -> LDS slab (operand buffers are dead after the last barrier) ---
+  float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
-  if (wave >= 2) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        *reinterpret_cast<float4*>(slab_at(wave - 2, i * 16 + lm, j * 16 + ln)) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-  }
+    for (int j = 0; j < FN; ++j)
+      *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
   __syncthreads();
-  if (wave < 2) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        float4* q = reinterpret_cast<float4*>(slab_at(wave, i * 16 + lm, j * 16 + ln));
-        const float4 o = *q;
-        *q = make_float4(acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w);
-      }
-  }
-  __syncthreads();
-
-  // ---- epilogue on the summed tile: items of 8 outputs per thread ---------------
-  const float* s0 = slab;
-  const float* s1 = slab + (size_t)BM * LDS_LD;
-  epi.template run<BM, BN, LDS_LD>(s0, s1, m0, n0, tid);
+  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid);
 }
 
 // ----------------------------------------------------------------------------
-// Epilogues.  run<BM,BN,LD>(s0, s1, m0, n0, tid): tile value (m,n) = s0[m*LD+n] + s1[m*LD+n].
+// Variant B: LDS-DMA ("global_load_lds") staging.  Ablation of the register-staged
+// kernel above (tools/ubench/gemm_bench.hip, MSD_ABL=4) shows ~45 % of its time is the
+// ds_write pass (ds_write_b128 sustains only ~79 B/clk/CU and sits in front of the
+// MFMAs in every wave).  Here the memory pipeline writes the tiles into LDS itself:
+// no staging VGPRs, no ds_write, NS-deep LDS ring, one raw s_barrier per K-tile and a
+// COUNTED s_waitcnt vmcnt(N) so the younger tiles' DMAs stay in flight across it.
+// The DMA destination is wave-uniform base + lane*16, i.e. 8 rows x 128 B land
+// row-major; the XOR swizzle that makes ds_read_b128 conflict-free is therefore
+// applied to the per-lane SOURCE address (lane (r, c') fetches global chunk c' ^ r).
+// ----------------------------------------------------------------------------
+template <int NP, int BM, int BN, int NS, class Epi>
+__global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi epi) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = NP * (A_BYTES + B_BYTES);
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // DMA instructions per wave per plane
+  constexpr int PW = NP * (A_LD + B_LD);          // DMA instructions per wave per K-tile
+  constexpr int LDS_LD = BN + kSlabPad;
+  static_assert(BM * LDS_LD * 4 <= NS * STAGE_BYTES, "epilogue slab must fit the operand LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbm = p.M / BM, nbn = p.N / BN;
+  int bm, bn;
+  {
+    const int b = blockIdx.x;
+    if ((nbn & 7) == 0) {
+      const int xcd = b & 7, t = b >> 3;
+      bm = t % nbm;
+      bn = (t / nbm) * 8 + xcd;
+    } else {
+      bm = b % nbm;
+      bn = b / nbm;
+    }
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
+  // B plane; lane (r = lane>>3, c' = lane&7) fetches global chunk c' ^ r of row 8i + r.
+  const int r8 = lane >> 3, csrc = (lane & 7) ^ r8;
+  const bf16_t* ga[NP];
+  const bf16_t* gb[NP];
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+    ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8;
+    gb[pl] = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8;
+  }
+  const size_t a_step = (size_t)8 * p.lda, b_step = (size_t)8 * p.ldb;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define MSD_D_ISSUE(KT, BUF)                                                                \
+  {                                                                                         \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                               \
+    const int k0_ = (KT) * kGemmBK;                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                     \
+      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                      \
+          __builtin_amdgcn_global_load_lds((gptr_t)(ga[pl] + i * a_step + k0_),             \
+              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, 0);  \
+      _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                      \
+          __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl] + i * b_step + k0_),             \
+              (lptr_t)(base_ + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * i) * 128), 16, 0, 0); \
+    }                                                                                       \
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / kGemmBK;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) MSD_D_ISSUE(s, s)
+
+  int buf = 0;  // LDS ring slot of tile kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt's DMAs are the oldest outstanding; up to NS-2 younger tiles stay in flight
+    if (kt + NS - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's part of tile kt landed; compute(kt-1) done everywhere
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NS - 1 < nk) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      MSD_D_ISSUE(kt + NS - 1, nb)   // into the slot compute(kt-1) just released
+    }
+    const char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      mfma_bf16x8 fa[NP][FM], fb[NP][FN];
+      const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          fa[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(
+              base + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c));
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          fb[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(
+              base + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+          if (NP == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NP - 1][j], fa[0][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[NP - 1][i], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    buf = (buf + 1 == NS) ? 0 : buf + 1;
+  }
+#undef MSD_D_ISSUE
+  __syncthreads();  // all fragment reads done before the slab overwrites the ring
+
+  float* slab = reinterpret_cast<float*>(smem);
+  const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  __syncthreads();
+  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid);
+}
+
+// ----------------------------------------------------------------------------
+// Epilogues.  run<BM,BN,LD>(slab, m0, n0, tid): tile value (m,n) = slab[m*LD+n].
 // ----------------------------------------------------------------------------
 template <int LD>
-__device__ __forceinline__ void tile_row8(const float* s0, const float* s1, int m, int n, float v[8]) {
+__device__ __forceinline__ void tile_row8(const float* s0, int m, int n, float v[8]) {
   const float4 a0 = *reinterpret_cast<const float4*>(s0 + m * LD + n);
   const float4 a1 = *reinterpret_cast<const float4*>(s0 + m * LD + n + 4);
-  const float4 b0 = *reinterpret_cast<const float4*>(s1 + m * LD + n);
-  const float4 b1 = *reinterpret_cast<const float4*>(s1 + m * LD + n + 4);
-  v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
-  v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+  v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
+  v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
 }
 
 template <int NP>
@@ -230,11 +425,11 @@ struct EpiStoreBf16 {
   bf16_t* out[2];
   int ldc;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, const float* s1, int m0, int n0, int tid) const {
+  __device__ void run(const float* s0, int m0, int n0, int tid) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
-      tile_row8<LD>(s0, s1, m, n, v);
+      tile_row8<LD>(s0, m, n, v);
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
     }
   }
@@ -249,12 +444,12 @@ struct EpiQKV {
   bf16_t* vt[2];
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, const float* s1, int m0, int n0, int tid) const {
+  __device__ void run(const float* s0, int m0, int n0, int tid) const {
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
         const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
         float v[8];
-        tile_row8<LD>(s0, s1, m, n, v);
+        tile_row8<LD>(s0, m, n, v);
         store_bf16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
       }
     } else {
@@ -264,7 +459,7 @@ struct EpiQKV {
         const int n = item / (BM / 8), mm = (item % (BM / 8)) * 8;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n] + s1[(mm + e) * LD + n];
+        for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
         const int mg = m0 + mm, seg = mg / seg_len, key = mg % seg_len;
         bf16_t* base[2];
         const size_t row = ((size_t)seg * vt_rows + (n0 + n - v_start)) * vt_ld + (key & ~15);
@@ -293,11 +488,11 @@ struct EpiResidual {
   float* x;
   int ldx;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, const float* s1, int m0, int n0, int tid) const {
+  __device__ void run(const float* s0, int m0, int n0, int tid) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
-      tile_row8<LD>(s0, s1, m, n, v);
+      tile_row8<LD>(s0, m, n, v);
       float4* px = reinterpret_cast<float4*>(x + (size_t)(m0 + m) * ldx + n0 + n);
       float4 a = px[0], b = px[1];
       a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3];
@@ -312,11 +507,11 @@ struct EpiStoreF32 {
   float* out;
   int ldc;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, const float* s1, int m0, int n0, int tid) const {
+  __device__ void run(const float* s0, int m0, int n0, int tid) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
-      tile_row8<LD>(s0, s1, m, n, v);
+      tile_row8<LD>(s0, m, n, v);
       float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
       po[0] = make_float4(v[0], v[1], v[2], v[3]);
       po[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -333,15 +528,15 @@ struct EpiGeglu {
   bf16_t* out[2];
   int ldc;  // = F
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, const float* s1, int m0, int n0, int tid) const {
+  __device__ void run(const float* s0, int m0, int n0, int tid) const {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
       const int pc = (j / 16) * 32 + (j % 16);
       float a[8], b[8], v[8];
-      tile_row8<LD>(s0, s1, m, pc, a);
-      tile_row8<LD>(s0, s1, m, pc + 16, b);
+      tile_row8<LD>(s0, m, pc, a);
+      tile_row8<LD>(s0, m, pc + 16, b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v);
@@ -349,13 +544,49 @@ struct EpiGeglu {
   }
 };
 
-template <int NP, int BM, int BN, int DEPTH, bool PIN, class Epi>
+template <int NP, int BM, int BN, int R, class Epi>
+constexpr int gemm_bf16_smem() { return 2 * NP * (BM + BN) * 128; }
+
+// one-time opt-in to > 64 KiB dynamic LDS; call for every instantiation OUTSIDE stream capture
+template <int NP, int BM, int BN, int R, class Epi>
+inline hipError_t gemm_bf16_prepare() {
+  constexpr int smem = gemm_bf16_smem<NP, BM, BN, R, Epi>();
+  if (smem < 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<NP, BM, BN, R, Epi>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+template <int NP, int BM, int BN, int R, class Epi>
 inline hipError_t launch_gemm_bf16(const GemmParams& p, const Epi& epi, hipStream_t stream) {
-  constexpr int smem = 2 * BM * (BN + kSlabPad) * 4;
-  static_assert(smem <= 64 * 1024, "tile needs the large-LDS attribute");
-  auto kern = gemm_bf16_kernel<NP, BM, BN, DEPTH, PIN, Epi>;
+  // (> 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, set once in
+  //  msd_api.hip:set_func_attrs -- never during stream capture)
+  constexpr int smem = gemm_bf16_smem<NP, BM, BN, R, Epi>();
+  auto kern = gemm_bf16_kernel<NP, BM, BN, R, Epi>;
+  static const hipError_t attr = gemm_bf16_prepare<NP, BM, BN, R, Epi>();
+  if (attr != hipSuccess) return attr;
   const int grid = (p.M / BM) * (p.N / BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p, epi);
+  return hipGetLastError();
+}
+
+template <int NP, int BM, int BN, int NS, class Epi>
+constexpr int gemm_bf16_dma_smem() { return NS * NP * (BM + BN) * 128; }
+
+template <int NP, int BM, int BN, int NS, class Epi>
+inline hipError_t gemm_bf16_dma_prepare() {
+  constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
+  if (smem < 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+template <int NP, int BM, int BN, int NS, class Epi>
+inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipStream_t stream) {
+  constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
+  static const hipError_t attr = gemm_bf16_dma_prepare<NP, BM, BN, NS, Epi>();
+  if (attr != hipSuccess) return attr;
+  const int grid = (p.M / BM) * (p.N / BN);
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
 }
 

@@ -273,22 +273,29 @@ GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, 
   return p;
 }
 
-// Tile selection (gemm_bf16.h): wide-N projections (QKV, gated MLP input) have
-// plenty of 64x64 tiles; the N = D projections get BM = 32 to double the block count.
-template <int NP, int BM> struct Tile {
-  static constexpr int DEPTH = (NP == 1) ? 4 : (BM == 64 ? 2 : 3);
-};
+// Kernel selection (gemm_bf16.h; numbers from tools/ubench/gemm_bench.hip, bf16x3): the
+// LDS-DMA variant with 64 x 64 tiles everywhere; a 2-deep ring (64 KiB -> two blocks per
+// CU) for the wide-N projections whose grids exceed the CU count (QKV, gated MLP input),
+// a 3-deep ring (one block per CU, longer prefetch distance) for the N = D projections.
+template <int NP, bool WIDE> struct GemmCfg { static constexpr int NS = (NP == 2 && WIDE) ? 2 : 3; };
 
-template <int NP, int BM, class Epi>
+template <int NP, bool WIDE, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi) {
-  static const bool pin = [] { const char* v = getenv("MSD_GEMM_PIN"); return v ? atoi(v) != 0 : true; }();
   c.begin(kc);
-  hipError_t e = pin
-      ? launch_gemm_bf16<NP, BM, 64, Tile<NP, BM>::DEPTH, true, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s)
-      : launch_gemm_bf16<NP, BM, 64, Tile<NP, BM>::DEPTH, false, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
+  hipError_t e = launch_gemm_bf16_dma<NP, 64, 64, GemmCfg<NP, WIDE>::NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
+}
+
+template <int NP>
+hipError_t prepare_gemms() {
+  hipError_t e = hipSuccess, r;
+#define PREP(WIDE, EPI) if ((r = gemm_bf16_dma_prepare<NP, 64, 64, GemmCfg<NP, WIDE>::NS, EPI>()) != hipSuccess) e = r;
+  PREP(true, EpiQKV<NP>) PREP(true, EpiGeglu<NP>)
+  PREP(false, EpiResidual) PREP(false, EpiStoreBf16<NP>) PREP(false, EpiStoreF32)
+#undef PREP
+  return e;
 }
 
 template <int NP>
@@ -482,16 +489,16 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     eq.qk[0] = m->eqk.p[0]; eq.qk[1] = m->eqk.p[NP - 1];
     eq.vt[0] = m->evt.p[0]; eq.vt[1] = m->evt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = m->Lenc_pad; eq.vt_ld = m->Lenc_pad; eq.vt_rows = J;
-    gemm<NP, 64>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq);
+    gemm<NP, true>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq);
     const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
     attention<NP, 8>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->evt, m->Lenc_pad, 0, m->eao, J,
                      m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
-    gemm<NP, 32>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
+    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
     norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->eg.p[0]; eg.out[1] = m->eg.p[NP - 1]; eg.ldc = F;
-    gemm<NP, 64>(c, KC_GEMM_MLP_IN, m->eh, D, lw.mlp.wi, D, rows, 2 * F, D, eg);
-    gemm<NP, 32>(c, KC_GEMM_MLP_OUT, m->eg, F, lw.mlp.wo, F, rows, D, F, EpiResidual{m->ex, D});
+    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->eh, D, lw.mlp.wi, D, rows, 2 * F, D, eg);
+    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->eg, F, lw.mlp.wo, F, rows, D, F, EpiResidual{m->ex, D});
   }
 }
 
@@ -579,7 +586,7 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
       ek.qk[0] = m->kc.p[0] + koff; ek.qk[1] = m->kc.p[NP - 1] + koff;
       ek.vt[0] = m->vtc.p[0] + koff; ek.vt[1] = m->vtc.p[NP - 1] + koff;
       ek.ld_qk = J; ek.v_start = J; ek.seg_len = m->S_pad; ek.vt_ld = m->S_pad; ek.vt_rows = J;
-      gemm<NP, 64>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek);
+      gemm<NP, true>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek);
     }
     m->h_nkeys_cross[b] = Sv;
   }
@@ -606,17 +613,17 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
     eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
-    gemm<NP, 64>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    gemm<NP, true>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
     const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
     attention<NP, 2>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, m->vt, T,
                      (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
-    gemm<NP, 32>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
+    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
-      gemm<NP, 32>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, false>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -624,14 +631,14 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP, 8>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, vt, m->S_pad,
                        (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
-      gemm<NP, 32>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
+      gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
     // (iii) MLP block (network.py:241-256)
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
-    gemm<NP, 64>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
-    gemm<NP, 32>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
+    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
   }
   // decoder_norm + spec_out_dense in fp32 (network.py:445-456)
   norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
@@ -669,6 +676,8 @@ void set_func_attrs() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<2, 8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+  (void)prepare_gemms<1>();
+  (void)prepare_gemms<2>();
 }
 
 }  // namespace
@@ -1088,7 +1097,7 @@ void split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t s) {
 
 int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev, int M,
                      int N, int K, void* stream) {
-  if (M % 64 || N % 64 || K % 32 || M <= 0 || N <= 0 || K <= 0) return MSD_ERR_INVALID_ARGUMENT;
+  if (M % 64 || N % 64 || K % 64 || M <= 0 || N <= 0 || K <= 0) return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int NP = precision == MSD_PREC_BF16X3 ? 2 : 1;
   Scratch sc;
@@ -1103,8 +1112,8 @@ int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, floa
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, w.p[0],
                      NP == 2 ? w.p[1] : (bf16_t*)nullptr, 0, 0, 0);
   hipError_t e;
-  if (NP == 2) e = launch_gemm_bf16<2, 64, 64, 2, true>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
-  else e = launch_gemm_bf16<1, 64, 64, 4, true>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  if (NP == 2) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  else e = launch_gemm_bf16_dma<1, 64, 64, 3>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
 }
