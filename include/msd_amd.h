@@ -176,7 +176,7 @@ int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev,
                     int m, int n, int k, void* stream);
 int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
                      const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
-                     int heads, void* stream); /* q [n_q, heads*64], k/v [n_keys, heads*64] */
+                     int heads, void* stream); /* q [n_q, heads*64] (n_q % 64 == 0), k/v [n_keys, heads*64] (n_keys % 32 == 0) */
 
 #ifdef __cplusplus
 }

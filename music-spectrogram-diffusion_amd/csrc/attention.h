@@ -5,20 +5,27 @@
 //   decoder cross-attention  256 x S_valid (<= 2304), key-padding mask realised by
 //                            dropping padded keys             (network.py:217-235)
 //   encoder self-attention   L_valid x L_valid                (network.py:131-137)
-// Keys beyond `n_keys` (padding up to a multiple of 32) get -1e30; a masked key has
-// weight exactly 0 in the reference too (exp(-1e10 + s - max) == 0 in fp32,
-// layers.py:341-346).  n_keys == 0 -> output 0 (layers.py:882-902).
+// Keys beyond `n_keys` get -1e30; a masked key has weight exactly 0 in the reference
+// too (exp(-1e10 + s - max) == 0 in fp32, layers.py:341-346).  n_keys == 0 -> output 0
+// (layers.py:882-902).
 //
-// Mapping: block = (32 query rows, one head, one segment), NW waves split the
-// key blocks round-robin; each wave runs online softmax over its 32-key blocks:
+// Mapping.  Block = (64 query rows, one head, one segment) = 8 waves = 2 query
+// blocks x 4 key groups.  K and V^T are streamed through an LDS ring in stages of
+// 128 keys by LDS-DMA (global_load_lds, full 128/256-byte rows: the per-CU vector
+// memory path moves 43 B/clk for whole lines but ~17 B/clk for MFMA-fragment-shaped
+// gathers, tools/ubench/load_patterns.hip), one raw barrier per stage, counted
+// s_waitcnt vmcnt(N).  Wave (qb, kg) runs online softmax over key block kg of every
+// stage for query block qb:
 //   S^T[key][q]  = K_blk . Q^T        v_mfma_f32_32x32x16_bf16, A = K rows, B = Q rows
 //   O^T[d][q]   += V^T_blk . P^T      A = V^T rows (key axis pre-permuted), B = P^T
 // In the 32x32 C layout a lane owns ONE query column (q = lane&31) and 16 of the
 // 32 keys, so max/sum/rescale are lane-local plus one lane^32 exchange, and the
-// P^T registers are already the B fragment of the second MFMA -- no LDS, no
-// cross-lane shuffles of P.  K, Q, V^T fragments are 16-byte global loads
-// (L2-resident: K/V of a layer are <= 7 MB).  Partial (m, l, O) of the NW waves
-// are merged through LDS.  NP = 2 runs every product as hi.hi + hi.lo + lo.hi.
+// P^T registers are already the B fragment of the second MFMA (that is what the
+// per-16 key permutation of V^T buys) -- no shuffles of P.  The (m, l, O) partials
+// of the 4 key groups are merged through LDS.  NP = 2 runs every product as
+// hi.hi + hi.lo + lo.hi.  Both LDS tiles are XOR-swizzled on the 16-byte chunk
+// index; since the DMA destination is lane-linear, the swizzle is applied to the
+// per-lane SOURCE address.
 #pragma once
 #include "common.h"
 #include "gemm_bf16.h"
@@ -32,9 +39,10 @@ struct AttnParams {
   bf16_t* o[2];         // [rows, ldo]
   const int* n_keys;    // [n_segs] valid keys per segment (device)
   int ldq, ldk, ldo, vt_ld;
-  int q_rows_per_seg;   // query rows per segment
+  int q_rows_per_seg;   // query rows per segment (multiple of 64)
   size_t k_seg_stride;  // elements between segments of k
   size_t vt_seg_stride; // elements between segments of vt
+  int k_rows;           // allocated key rows per segment (DMA source rows are clamped to it)
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag8;
@@ -43,26 +51,89 @@ __device__ __forceinline__ frag8 ld_frag(const bf16_t* p) {
   return as_frag(*reinterpret_cast<const uint4*>(p));
 }
 
-template <int NP, int NW>
-__global__ void __launch_bounds__(NW * 64) attention_kernel(AttnParams p) {
+#ifndef MSD_ATT_ABL
+#define MSD_ATT_ABL 0  // ablation switch for tools/ubench/attn_bench.hip; 0 = the product kernel
+#endif
+
+constexpr int kAttQB = 2, kAttKG = 4, kAttWaves = kAttQB * kAttKG;
+constexpr int kAttStageKeys = kAttKG * 32;             // 128 keys per LDS stage
+constexpr int kAttKBytes = kAttStageKeys * 128;        // K tile  [128 keys][64 d] bf16
+constexpr int kAttVBytes = 64 * kAttStageKeys * 2;     // V^T tile [64 d][128 keys] bf16
+constexpr int kAttOLD = 68;                            // merge slab row stride (floats)
+constexpr int kAttWStride = 32 * kAttOLD + 64;         // per-wave merge slab (floats)
+
+template <int NP, int NS>
+constexpr int attention_smem() {
+  return (NS * NP * (kAttKBytes + kAttVBytes) > kAttWaves * kAttWStride * 4)
+             ? NS * NP * (kAttKBytes + kAttVBytes)
+             : kAttWaves * kAttWStride * 4;
+}
+
+template <int NP, int NS>
+__global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p) {
   constexpr float NEG = -1e30f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qb = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
+  constexpr int STAGE = NP * (kAttKBytes + kAttVBytes);
+  constexpr int PW = 4 * NP;  // DMA instructions per wave per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = wave / kAttKG, kg = wave % kAttKG;
+  const int blk = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
   const int nkeys = p.n_keys[seg];
-  const int nkb = (nkeys + 31) >> 5;
+  const int nst = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
 
-  const size_t qrow = (size_t)seg * p.q_rows_per_seg + qb * 32 + q_lane;
-  const bf16_t* kbase[NP];
-  const bf16_t* vbase[NP];
+  // ---- DMA source addressing -------------------------------------------------------
+  // K tile: instruction j (0..15) moves keys 8j..8j+7 of the stage, lane = (r = lane>>3, c' = lane&7),
+  //         source chunk c' ^ r (rows are 128 B = 8 chunks).  This wave issues j = 2*wave, 2*wave+1.
+  // V^T   : instruction j (0..15) moves rows d = 4j..4j+3, lane = (r = lane>>4, c' = lane&15),
+  //         source chunk c' ^ (d & 15) (rows are 256 B = 16 chunks).
+  const int kr = lane >> 3, kc = (lane & 7) ^ kr;
+  const int vr = lane >> 4;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const bf16_t* kseg[NP];
+  const bf16_t* vseg[NP];
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+    kseg[pl] = p.k[pl] + (size_t)seg * p.k_seg_stride + head * 64 + kc * 8;
+    vseg[pl] = p.vt[pl] + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64) * p.vt_ld;
+  }
+  const int last_row = p.k_rows - 1, last_kcol = p.vt_ld - 8;
+
+#define MSD_A_ISSUE(ST, BUF)                                                                      \
+  {                                                                                               \
+    char* base_ = smem + (BUF) * STAGE;                                                           \
+    const int kb_ = (ST) * kAttStageKeys;                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                           \
+      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                          \
+        const int j_ = 2 * wave + jj;                                                             \
+        int row_ = kb_ + 8 * j_ + kr;                                                             \
+        row_ = row_ < last_row ? row_ : last_row;                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kseg[pl] + (size_t)row_ * p.ldk),               \
+            (lptr_t)(base_ + pl * kAttKBytes + j_ * 1024), 16, 0, 0);                             \
+        const int d_ = 4 * j_ + vr;                                                               \
+        int col_ = kb_ + (((lane & 15) ^ (d_ & 15)) << 3);                                        \
+        col_ = col_ < last_kcol ? col_ : last_kcol;                                               \
+        __builtin_amdgcn_global_load_lds((gptr_t)(vseg[pl] + (size_t)d_ * p.vt_ld + col_),        \
+            (lptr_t)(base_ + NP * kAttKBytes + pl * kAttVBytes + j_ * 1024), 16, 0, 0);           \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nst) MSD_A_ISSUE(s, s)
+
+  // ---- Q fragments (B operand of S^T = K.Q^T), straight from global -------------------
+  const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * 64 + qb * 32 + q_lane;
   frag8 qf[NP][4];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
     const bf16_t* qp = p.q[pl] + qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[pl][s] = ld_frag(qp + s * 16);
-    kbase[pl] = p.k[pl] + (size_t)seg * p.k_seg_stride + head * 64 + hi * 8;
-    vbase[pl] = p.vt[pl] + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64 + q_lane) * p.vt_ld + hi * 8;
   }
 
   f32x16 o0, o1;
@@ -70,164 +141,183 @@ __global__ void __launch_bounds__(NW * 64) attention_kernel(AttnParams p) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = NEG, l_run = 0.f;
 
-  for (int kb = wave; kb < nkb; kb += NW) {
-    // ---- S^T = K . Q^T ----------------------------------------------------
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    frag8 kf[NP][4];
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-      const bf16_t* kp = kbase[pl] + (size_t)(kb * 32 + q_lane) * p.ldk;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) kf[pl][st] = ld_frag(kp + st * 16);
+  int buf = 0;
+  for (int st = 0; st < nst; ++st) {
+    if (st + NS - 2 < nst) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // V^T fragments issued early so their latency hides under QK^T + softmax
-    frag8 vf[NP][2][2];
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          vf[pl][db][ks] = ld_frag(vbase[pl] + (size_t)db * 32 * p.vt_ld + kb * 32 + ks * 16);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][st], qf[0][st], s, 0, 0, 0);
-      if (NP == 2) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][st], qf[NP - 1][st], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NP - 1][st], qf[0][st], s, 0, 0, 0);
-      }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (st + NS - 1 < nst && MSD_ATT_ABL != 3) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      MSD_A_ISSUE(st + NS - 1, nb)
     }
-    // lane owns keys kb*32 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
-    float bmax = NEG;
+    const int kb0 = st * kAttStageKeys + kg * 32;  // first key of this wave's block
+    if (kb0 < nkeys) {
+      const char* kt = smem + buf * STAGE;
+      const char* vt = kt + NP * kAttKBytes;
+      // ---- S^T = K . Q^T ------------------------------------------------------------
+      f32x16 s;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (key >= nkeys) s[r] = NEG;
-      bmax = fmaxf(bmax, s[r]);
-    }
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-    const float m_new = fmaxf(m_run, bmax);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-    float pv[16];
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const int krow = kg * 32 + q_lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = __expf(s[r] - m_new);
-      psum += pv[r];
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      for (int sx = 0; sx < 4; ++sx) {
+        frag8 kf[NP];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    // ---- P^T fragments (k-slot j of step ks <-> register 8*ks + j) ----------
-    frag8 pf[NP][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint32_t wh[4], wl[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf16_t h0, l0, h1, l1;
+        for (int pl = 0; pl < NP; ++pl)
+          kf[pl] = *reinterpret_cast<const frag8*>(kt + pl * kAttKBytes + krow * 128 +
+                                                   (((2 * sx + hi) ^ (krow & 7)) << 4));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][sx], s, 0, 0, 0);
         if (NP == 2) {
-          split_bf16(pv[8 * ks + 2 * j], h0, l0);
-          split_bf16(pv[8 * ks + 2 * j + 1], h1, l1);
-          wl[j] = pack2(l0, l1);
-        } else {
-          h0 = f2bf(pv[8 * ks + 2 * j]);
-          h1 = f2bf(pv[8 * ks + 2 * j + 1]);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[NP - 1][sx], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NP - 1], qf[0][sx], s, 0, 0, 0);
         }
-        wh[j] = pack2(h0, h1);
       }
-      pf[0][ks] = as_frag(make_uint4(wh[0], wh[1], wh[2], wh[3]));
-      if (NP == 2) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
-    }
-    // ---- O^T += V^T . P^T ---------------------------------------------------
+      // lane owns keys kb0 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
+      float bmax = NEG;
+      if (kb0 + 32 > nkeys) {  // only the last, ragged key block needs the bound
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0][ks], pf[0][ks], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1][ks], pf[0][ks], o1, 0, 0, 0);
-      if (NP == 2) {
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0][ks], pf[NP - 1][ks], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1][ks], pf[NP - 1][ks], o1, 0, 0, 0);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][0][ks], pf[0][ks], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][1][ks], pf[0][ks], o1, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= nkeys) s[r] = NEG;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+      const float m_new = fmaxf(m_run, bmax);
+      const float alpha = fast_exp(m_run - m_new);
+      float psum = 0.f;
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = (MSD_ATT_ABL == 2) ? (s[r] - m_new) : fast_exp(s[r] - m_new);
+        psum += pv[r];
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // ---- P^T fragments (k-slot j of step ks <-> register 8*ks + j) ----------------
+      frag8 pf[NP][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint32_t wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16_t h0, l0, h1, l1;
+          if (NP == 2) {
+            split_bf16(pv[8 * ks + 2 * j], h0, l0);
+            split_bf16(pv[8 * ks + 2 * j + 1], h1, l1);
+            wl[j] = pack2(l0, l1);
+          } else {
+            h0 = f2bf(pv[8 * ks + 2 * j]);
+            h1 = f2bf(pv[8 * ks + 2 * j + 1]);
+          }
+          wh[j] = pack2(h0, h1);
+        }
+        pf[0][ks] = as_frag(make_uint4(wh[0], wh[1], wh[2], wh[3]));
+        if (NP == 2) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
+      }
+      // ---- O^T += V^T . P^T -----------------------------------------------------------
+      if (MSD_ATT_ABL == 4) { asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1])); } else
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frag8 vf[NP][2];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int d = db * 32 + q_lane;
+            vf[pl][db] = *reinterpret_cast<const frag8*>(
+                vt + pl * kAttVBytes + d * 256 + (((kg * 4 + ks * 2 + hi) ^ (d & 15)) << 4));
+          }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pf[0][ks], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], pf[0][ks], o1, 0, 0, 0);
+        if (NP == 2) {
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pf[NP - 1][ks], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], pf[NP - 1][ks], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][0], pf[0][ks], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][1], pf[0][ks], o1, 0, 0, 0);
+        }
       }
     }
+    buf = (buf + 1 == NS) ? 0 : buf + 1;
   }
+#undef MSD_A_ISSUE
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
 
-  // ---- merge the NW partial results through LDS ------------------------------
-  // layout per wave: O [32 q][64 d + 4 pad] fp32, then m[32], l[32]
-  constexpr int OLD = 68;
-  constexpr int WSTRIDE = 32 * OLD + 64;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);
-  float* mine = sm + wave * WSTRIDE;
+  // ---- merge the 4 key-group partials of each query block through LDS --------------
+  // per wave: O [32 q][64 d + 4 pad] fp32, then m[32], l[32]
+  float* sm = reinterpret_cast<float*>(smem);
+  float* mine = sm + wave * kAttWStride;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     // registers 4g..4g+3 are d = 8g + 4hi + 0..3 (rows of the 32x32 C tile)
     const int d = 8 * g + 4 * hi;
-    *reinterpret_cast<float4*>(mine + q_lane * OLD + d) =
+    *reinterpret_cast<float4*>(mine + q_lane * kAttOLD + d) =
         make_float4(o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
-    *reinterpret_cast<float4*>(mine + q_lane * OLD + 32 + d) =
+    *reinterpret_cast<float4*>(mine + q_lane * kAttOLD + 32 + d) =
         make_float4(o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
   }
   if (hi == 0) {
-    mine[32 * OLD + q_lane] = m_run;
-    mine[32 * OLD + 32 + q_lane] = l_run;
+    mine[32 * kAttOLD + q_lane] = m_run;
+    mine[32 * kAttOLD + 32 + q_lane] = l_run;
   }
   __syncthreads();
-  // 32 q x 8 groups of 8 d = 256 work items
-  for (int item = threadIdx.x; item < 256; item += NW * 64) {
-    const int q = item >> 3, d0 = (item & 7) * 8;
+  // 2 query blocks x 32 q x 8 groups of 8 d = 512 work items = one per thread
+  {
+    const int item = tid;
+    const int mqb = item >> 8, q = (item >> 3) & 31, d0 = (item & 7) * 8;
+    const float* wbase = sm + (size_t)(mqb * kAttKG) * kAttWStride;
     float mt = NEG;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mt = fmaxf(mt, sm[w * WSTRIDE + 32 * OLD + q]);
+    for (int w = 0; w < kAttKG; ++w) mt = fmaxf(mt, wbase[w * kAttWStride + 32 * kAttOLD + q]);
     float lt = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float* ws = sm + w * WSTRIDE;
-      const float f = __expf(ws[32 * OLD + q] - mt);
-      lt += ws[32 * OLD + 32 + q] * f;
-      const float4 a = *reinterpret_cast<const float4*>(ws + q * OLD + d0);
-      const float4 b = *reinterpret_cast<const float4*>(ws + q * OLD + d0 + 4);
+    for (int w = 0; w < kAttKG; ++w) {
+      const float* ws = wbase + w * kAttWStride;
+      const float f = fast_exp(ws[32 * kAttOLD + q] - mt);
+      lt += ws[32 * kAttOLD + 32 + q] * f;
+      const float4 a = *reinterpret_cast<const float4*>(ws + q * kAttOLD + d0);
+      const float4 b = *reinterpret_cast<const float4*>(ws + q * kAttOLD + d0 + 4);
       acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
       acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
     }
     const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
-    const size_t off = ((size_t)seg * p.q_rows_per_seg + qb * 32 + q) * p.ldo + head * 64 + d0;
-    uint32_t wh[4], wl[4];
+    const size_t off = ((size_t)seg * p.q_rows_per_seg + blk * 64 + mqb * 32 + q) * p.ldo + head * 64 + d0;
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bf16_t h0, l0, h1, l1;
-      const float v0 = acc[2 * e] * inv, v1 = acc[2 * e + 1] * inv;
-      if (NP == 2) {
-        split_bf16(v0, h0, l0);
-        split_bf16(v1, h1, l1);
-        wl[e] = pack2(l0, l1);
-      } else {
-        h0 = f2bf(v0);
-        h1 = f2bf(v1);
-      }
-      wh[e] = pack2(h0, h1);
-    }
-    *reinterpret_cast<uint4*>(p.o[0] + off) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-    if (NP == 2) *reinterpret_cast<uint4*>(p.o[NP - 1] + off) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+    store_bf16x8<NP>(p.o, off, v);
   }
 }
 
-template <int NP, int NW>
-inline hipError_t launch_attention(const AttnParams& p, int q_blocks, int heads, int segs,
-                                   hipStream_t stream) {
-  // (> 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, set once in
-  //  msd_api.hip:set_func_attrs -- never during stream capture)
-  constexpr int smem = NW * (32 * 68 + 64) * 4;
-  auto kern = attention_kernel<NP, NW>;
-  hipLaunchKernelGGL(kern, dim3(q_blocks, heads, segs), dim3(NW * 64), smem, stream, p);
+template <int NP, int NS>
+inline hipError_t attention_prepare() {
+  constexpr int smem = attention_smem<NP, NS>();
+  if (smem < 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+// NS: LDS ring depth (NP = 2: one stage is 64 KiB -> NS = 2; NP = 1: 32 KiB -> NS = 3)
+template <int NP>
+inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hipStream_t stream) {
+  constexpr int NS = (NP == 2) ? 2 : 3;
+  constexpr int smem = attention_smem<NP, NS>();
+  static const hipError_t attr = attention_prepare<NP, NS>();
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3(p.q_rows_per_seg / 64, heads, segs),
+                     dim3(kAttWaves * 64), smem, stream, p);
   return hipGetLastError();
 }
 

@@ -12,12 +12,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumu
 
 constexpr int kWave = 64;
 
-// round-to-nearest-even float -> bf16 bits (finite inputs; NaN kept quiet)
+// round-to-nearest-even float -> bf16 bits.  The native cast lowers to
+// v_cvt_pk_bf16_f32 (two values per instruction); hand-written bit arithmetic costs
+// ~8 VALU ops per value and made the attention kernel VALU-bound.
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
@@ -42,6 +42,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   const float c = 0.7978845608028654f;
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
 }
+
+// e^x as one v_exp_f32 (2^(x log2 e)); relative error ~|x| 2^-24, used for softmax where x <= 0
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 __device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -322,9 +322,9 @@ void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const flo
   c.end(KC_NORM);
 }
 
-template <int NP, int NW>
+template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
-               size_t k_seg_stride, const Planes& vt, int vt_ld, size_t vt_seg_stride,
+               size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
                int segs) {
   AttnParams p;
@@ -334,9 +334,9 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2
   }
   p.n_keys = n_keys; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
   p.q_rows_per_seg = q_rows_per_seg; p.k_seg_stride = k_seg_stride;
-  p.vt_seg_stride = vt_seg_stride;
+  p.vt_seg_stride = vt_seg_stride; p.k_rows = k_rows;
   c.begin(kc);
-  hipError_t e = launch_attention<NP, NW>(p, q_rows_per_seg / 32, heads, segs, c.s);
+  hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
@@ -491,8 +491,8 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = m->Lenc_pad; eq.vt_ld = m->Lenc_pad; eq.vt_rows = J;
     gemm<NP, true>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq);
     const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
-    attention<NP, 8>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->evt, m->Lenc_pad, 0, m->eao, J,
-                     m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
+    attention<NP>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->Lenc_pad, m->evt, m->Lenc_pad, 0, m->eao, J,
+                  m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
     gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
     norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
     EpiGeglu<NP> eg;
@@ -615,8 +615,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
     gemm<NP, true>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
     const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
-    attention<NP, 2>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, m->vt, T,
-                     (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
+    attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
+                  (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
     gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
@@ -629,8 +629,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
       Planes vt;
       vt.p[0] = m->vtc.p[0] + loff;
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
-      attention<NP, 8>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, vt, m->S_pad,
-                       (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
+      attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
+                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
       gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
     // (iii) MLP block (network.py:241-256)
@@ -670,12 +670,9 @@ void enqueue_step(Ctx& c, int batch) {
 }
 
 void set_func_attrs() {
-  // large dynamic LDS for the 8-wave attention merge buffer
-  const int smem8 = 8 * (32 * 68 + 64) * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<1, 8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<2, 8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+  // opt in to > 64 KiB dynamic LDS once, outside any stream capture
+  (void)attention_prepare<1, 3>();
+  (void)attention_prepare<2, 2>();
   (void)prepare_gemms<1>();
   (void)prepare_gemms<2>();
 }
@@ -1130,7 +1127,7 @@ int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev, int M,
 
 int msd_op_attention(int precision, const float* q_dev, const float* k_dev, const float* v_dev,
                      float* o_dev, int n_q, int n_keys, int n_keys_valid, int heads, void* stream) {
-  if (n_q % 32 || n_keys % 32 || n_q <= 0 || n_keys <= 0 || heads <= 0 || n_keys_valid < 0 ||
+  if (n_q % 64 || n_keys % 32 || n_q <= 0 || n_keys <= 0 || heads <= 0 || n_keys_valid < 0 ||
       n_keys_valid > n_keys)
     return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1167,9 +1164,8 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
     p.q[i] = q.p[j]; p.k[i] = k.p[j]; p.vt[i] = vt.p[j]; p.o[i] = o.p[j];
   }
   p.n_keys = d_nk; p.ldq = J; p.ldk = J; p.ldo = J; p.vt_ld = n_keys; p.q_rows_per_seg = n_q;
-  p.k_seg_stride = 0; p.vt_seg_stride = 0;
-  hipError_t e = NP == 2 ? launch_attention<2, 4>(p, n_q / 32, heads, 1, s)
-                         : launch_attention<1, 4>(p, n_q / 32, heads, 1, s);
+  p.k_seg_stride = 0; p.vt_seg_stride = 0; p.k_rows = n_keys;
+  hipError_t e = NP == 2 ? launch_attention<2>(p, heads, 1, s) : launch_attention<1>(p, heads, 1, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
                      o.p[0], NP == 2 ? o.p[1] : (const bf16_t*)nullptr, o_dev, (int64_t)n_q * J);

@@ -55,8 +55,9 @@ def test_gemm_f32(env, m, n, k):
 
 
 @pytest.mark.parametrize('prec,tol', [('bf16', 3e-2), ('bf16x3', 3e-5)])
-@pytest.mark.parametrize('nq,nk,valid,heads', [(32, 32, 32, 1), (256, 256, 256, 2), (64, 2304, 2304, 3),
-                                               (64, 512, 301, 2), (32, 64, 1, 1), (32, 64, 0, 2)])
+@pytest.mark.parametrize('nq,nk,valid,heads', [(64, 32, 32, 1), (256, 256, 256, 2), (64, 2304, 2304, 3),
+                                               (128, 512, 301, 2), (64, 64, 1, 1), (64, 64, 0, 2),
+                                               (64, 160, 129, 1), (192, 1344, 1337, 2)])
 def test_attention(env, prec, tol, nq, nk, valid, heads):
   """Unscaled softmax(q k^T) v with a key-count bound (== the reference's -1e10
   padding bias, layers.py:341-346) and the all-masked -> 0 rule (layers.py:882-902)."""
@@ -85,7 +86,7 @@ def test_attention_spiked_key_forces_online_rescale(env):
   torch, native = env
   from oracle import backend, ops
   rng = np.random.default_rng(5)
-  nq, nk, heads = 32, 256, 1
+  nq, nk, heads = 64, 256, 1
   q = (rng.standard_normal((nq, 64)) * 0.3).astype(np.float32)
   k = (rng.standard_normal((nk, 64)) * 0.3).astype(np.float32)
   v = rng.standard_normal((nk, 64)).astype(np.float32)
