@@ -114,6 +114,7 @@ def main():
   ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
   ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
   ap.add_argument('--cfg-weight', type=float, default=5.0)
+  ap.add_argument('--batch', type=int, default=1, help='independent songs synthesized together per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample-steps', type=int, default=20)
   ap.add_argument('--profile-steps', type=int, default=3)
@@ -137,22 +138,24 @@ def main():
                             device_id=torch.device('cuda', local_rank))
 
   spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
-  model = msd_amd.InferenceModel('synthetic:0', spec, precision=args.precision)
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
+  nb = args.batch
   t_frames = spec.task_feature_lengths['targets']
   n_seg = args.warmup + args.steps
   # every rank plays its own synthetic song (different token streams per rank)
-  segs = [msd_amd.synthetic.segment_tokens(spec, 1000 * rank + k) for k in range(n_seg)]
+  segs = [np.concatenate([msd_amd.synthetic.segment_tokens(spec, 1000 * (rank * nb + b) + k) for b in range(nb)], 0)
+          for k in range(n_seg)]
   c_len = model.targets_context_length
   pred = None
   if c_len is not None:
-    pred = torch.zeros((1, c_len, 128), dtype=torch.float32, device=model.device)
+    pred = torch.zeros((nb, c_len, 128), dtype=torch.float32, device=model.device)
 
   def run_segment(k):
     nonlocal pred
     batch = {'encoder_input_tokens': segs[k]}
     if c_len is not None:
       batch['encoder_continuous_inputs'] = pred
-      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((1, c_len), np.int32)
+      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((nb, c_len), np.int32)
     out, _ = model.predict(batch, seed=0, segment=k, return_torch=True)
     if c_len is not None:
       pred = out
@@ -183,17 +186,17 @@ def main():
 
   result = None
   if rank == 0:
-    frames = world * args.steps * t_frames
+    frames = world * args.steps * t_frames * nb
     value = frames / elapsed
     audio_s = frames * 320 / 16000.0
     passes = 2 if args.cfg_weight != 1.0 else 1
     # ---- roofline of the dominant kernel (hipEvents on the launch stream) --------
     nm = model._get_native()
     toks = segs[-1]
-    s_valid = float((toks > 0).sum() + (c_len or 0))
+    s_valid = float((toks > 0).sum() / nb + (c_len or 0))
     with torch.cuda.device(model.device):
-      prof = nm.profile_steps(1, args.profile_steps, stream=model._stream.cuda_stream)
-    flops = class_flops(spec, s_valid, passes)
+      prof = nm.profile_steps(nb, args.profile_steps, stream=model._stream.cuda_stream)
+    flops = {k: v * nb for k, v in class_flops(spec, s_valid, passes).items()}
     per_class = {}
     for name, (ms, launches) in prof.items():
       if launches:
@@ -224,16 +227,16 @@ def main():
         'dtype': 'bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/norm/softmax/sampler)'
                  if args.precision == 'bf16x3' else 'bf16',
         'data': 'synthetic (seeded tokens, reference-initialiser weights, Philox noise)',
-        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, batch 1, segment-sequential with context '
-                               'hand-off, %d segments of %d frames per GPU'
-                               % (args.preset, args.num_steps, args.cfg_weight, args.steps, t_frames),
+        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, segment-sequential with '
+                               'context hand-off, %d segments of %d frames per song'
+                               % (args.preset, args.num_steps, args.cfg_weight, nb, args.steps, t_frames),
                    'precision': args.precision, 'parallelism': 'song-parallel x%d' % world},
         'encode_ms_per_segment': round(enc_s / args.steps * 1e3, 3),
         'sample_ms_per_segment': round(smp_s / args.steps * 1e3, 3),
         'roofline': roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-      batch = {'encoder_input_tokens': segs[-1]}
+      batch = {'encoder_input_tokens': segs[-1][:1]}
       if c_len is not None:
         batch['encoder_continuous_inputs'] = np.zeros((1, c_len, 128), np.float32)
         batch['encoder_continuous_mask'] = np.ones((1, c_len), np.int32)
