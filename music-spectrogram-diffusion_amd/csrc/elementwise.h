@@ -135,6 +135,16 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) p.step_ptr[1] = i - 1;
 }
 
+// g[step][slot][k] = gamma[k] * (film_scale[step][slot][k] + 1): the column multiplier of a
+// FiLM-modulated RMSNorm, tabulated for every step (folded-norm GEMM epilogues, gemm_bf16.h)
+__global__ void build_g_kernel(const float* film, const float* gamma, float* g, int n_steps, int slots,
+                               int slot, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_steps * D) return;
+  const int step = i / D, k = i % D;
+  g[((size_t)step * slots + slot) * D + k] = gamma[k] * (film[((size_t)step * slots + slot) * 2 * D + k] + 1.0f);
+}
+
 // step_ptr[0] <- step_ptr[1]  (double-buffered scan index: the sampler writes the
 // next index to slot 1 while other blocks of the same launch may still read slot 0)
 __global__ void advance_step_kernel(int* step_ptr) { step_ptr[0] = step_ptr[1]; }

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
   constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-byte loads per thread per plane
   constexpr int LDS_LD = BN + kSlabPad;
   static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must be a multiple of 32");
-  static_assert(BM * LDS_LD * 4 <= 2 * STAGE_BYTES, "epilogue slab must fit the operand LDS");
+  static_assert((BM * LDS_LD + BM) * 4 <= 2 * STAGE_BYTES, "epilogue slab must fit the operand LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   constexpr int A_LD = BM / 32, B_LD = BN / 32;   // DMA instructions per wave per plane
   constexpr int PW = NP * (A_LD + B_LD);          // DMA instructions per wave per K-tile
   constexpr int LDS_LD = BN + kSlabPad;
-  static_assert(BM * LDS_LD * 4 <= NS * STAGE_BYTES, "epilogue slab must fit the operand LDS");
+  static_assert((BM * LDS_LD + BM) * 4 <= NS * STAGE_BYTES, "epilogue slab must fit the operand LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -419,17 +419,58 @@ __device__ __forceinline__ void store_bf16x8(bf16_t* const* planes, size_t off, 
   if (NP == 2) *reinterpret_cast<uint4*>(planes[1] + off) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
 }
 
-// C (row-major bf16 planes) = acc
+// ----------------------------------------------------------------------------
+// Folded RMSNorm + FiLM (layers.py:632-666).  h = x * rstd[m] * g[k] + b[k] feeds a
+// bias-free Dense, so  h.W = rstd[m] * ((x (.) g).W) + (b.W):
+//   * the PRODUCER of x (residual epilogue below) also writes y = x (.) g as bf16
+//     planes -- g = gamma (.) (film_scale(step) + 1) of the NEXT norm -- and the
+//     per-64-column partial sums of squares of x;
+//   * the CONSUMER GEMM runs on y and its epilogue applies rstd[m] (from the partial
+//     sums) and the step-indexed vector b.W, tabulated at load time for every step.
+// This removes the separate norm kernel (and its round trip through HBM) in front of
+// every decoder projection.
+// ----------------------------------------------------------------------------
+struct RowScale {
+  const float* ssq = nullptr;   // [M][tiles] partial sums of squares of x; nullptr = no folding
+  int tiles = 0;
+  float inv_d = 0.f;
+  const float* bias = nullptr;  // base of the step-indexed bias table, or nullptr
+  int bias_step_stride = 0;     // elements between steps
+  const int* step_ptr = nullptr;
+};
+
+// rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier
+template <int BM>
+__device__ __forceinline__ const float* tile_rstd(const RowScale& r, float* rs, int m0, int tid) {
+  if (tid < BM) {
+    const float* q = r.ssq + (size_t)(m0 + tid) * r.tiles;
+    float acc = 0.f;
+    for (int t = 0; t < r.tiles; ++t) acc += q[t];
+    rs[tid] = 1.0f / sqrtf(acc * r.inv_d + 1e-6f);
+  }
+  __syncthreads();
+  return r.bias ? r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride : nullptr;
+}
+
+// C (row-major bf16 planes) = acc [* rstd[m] + bias[n]]
 template <int NP>
 struct EpiStoreBf16 {
   bf16_t* out[2];
   int ldc;
+  RowScale rsc;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
+    float* rs = s0 + BM * LD;
+    const float* bias = nullptr;
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
       tile_row8<LD>(s0, m, n, v);
+      if (rsc.ssq) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+      }
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
     }
   }
@@ -443,13 +484,21 @@ struct EpiQKV {
   bf16_t* qk[2];
   bf16_t* vt[2];
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
+  RowScale rsc;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
+    float* rs = s0 + BM * LD;
+    const float* bias = nullptr;
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
         const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
         float v[8];
         tile_row8<LD>(s0, m, n, v);
+        if (rsc.ssq) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+        }
         store_bf16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
       }
     } else {
@@ -460,6 +509,11 @@ struct EpiQKV {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
+        if (rsc.ssq) {
+          const float bn = bias ? bias[n0 + n] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[mm + e] + bn;
+        }
         const int mg = m0 + mm, seg = mg / seg_len, key = mg % seg_len;
         bf16_t* base[2];
         const size_t row = ((size_t)seg * vt_rows + (n0 + n - v_start)) * vt_ld + (key & ~15);
@@ -488,7 +542,7 @@ struct EpiResidual {
   float* x;
   int ldx;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -502,12 +556,63 @@ struct EpiResidual {
   }
 };
 
+// Residual add that also PRODUCES the folded-norm inputs of the next projection:
+//   x += acc ;  ssq[m][n0/64] = sum over this tile's 64 columns of x^2 ;
+//   y = x (.) g  as bf16 planes, g = g_lo for rows < split_row, g_hi otherwise
+//   (g pointer = base + step * step_stride; a null base skips y for that row range).
+template <int NP>
+struct EpiResidualNorm {
+  float* x;
+  int ldx;
+  bf16_t* y[2];
+  float* ssq;
+  int tiles;
+  const float* g_lo; int g_lo_stride;
+  const float* g_hi; int g_hi_stride;
+  int split_row;
+  const int* step_ptr;
+  template <int BM, int BN, int LD>
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
+    static_assert(BN == 64, "partial sums of squares are per 64-column tile");
+    const int step = *step_ptr;
+    const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
+    const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
+    for (int item = tid; item < BM * BN / 8; item += 256) {
+      const int m = item / 8, n = (item % 8) * 8;   // 8 consecutive lanes share a row
+      float v[8];
+      tile_row8<LD>(s0, m, n, v);
+      const int row = m0 + m, col = n0 + n;
+      float4* px = reinterpret_cast<float4*>(x + (size_t)row * ldx + col);
+      float4 a = px[0], b = px[1];
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+      v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      px[0] = make_float4(v[0], v[1], v[2], v[3]);
+      px[1] = make_float4(v[4], v[5], v[6], v[7]);
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 4, 64);
+      if ((item & 7) == 0) ssq[(size_t)row * tiles + (n0 >> 6)] = sq;
+      const float* g = row < split_row ? glo : ghi;
+      if (g) {
+        const float4 g0 = *reinterpret_cast<const float4*>(g + col);
+        const float4 g1 = *reinterpret_cast<const float4*>(g + col + 4);
+        v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
+        v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
+        store_bf16x8<NP>(y, (size_t)row * ldx + col, v);
+      }
+    }
+  }
+};
+
 // out fp32 [M, ldc] = acc
 struct EpiStoreF32 {
   float* out;
   int ldc;
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -527,16 +632,27 @@ template <int NP>
 struct EpiGeglu {
   bf16_t* out[2];
   int ldc;  // = F
+  RowScale rsc;  // bias table is indexed by PACKED column
   template <int BM, int BN, int LD>
-  __device__ void run(const float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
+    float* rs = s0 + BM * LD;
+    const float* bias = nullptr;
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
       const int pc = (j / 16) * 32 + (j % 16);
       float a[8], b[8], v[8];
       tile_row8<LD>(s0, m, pc, a);
       tile_row8<LD>(s0, m, pc + 16, b);
+      if (rsc.ssq) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a[e] = a[e] * rs[m] + (bias ? bias[n0 + pc + e] : 0.f);
+          b[e] = b[e] * rs[m] + (bias ? bias[n0 + pc + 16 + e] : 0.f);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v);

@@ -32,6 +32,15 @@ struct EpiF32Swish {  // nn.swish (network.py:385,391)
     out[(size_t)m * ldc + n] = v / (1.0f + expf(-v));
   }
 };
+// out[m][packed(n)] = v, packed(n) = (n/16)*32 + which*16 + n%16: the wi_0/wi_1 column
+// interleave of the gated-MLP weight (gemm_bf16.h EpiGeglu), for the folded FiLM-bias table
+struct EpiF32StoreGated {
+  float* out;
+  int ldc, which;
+  __device__ void operator()(int m, int n, float v) const {
+    out[(size_t)m * ldc + (n / 16) * 32 + which * 16 + (n % 16)] = v;
+  }
+};
 // decoder input: x[pass][m][:] = z[m] . W_in + pos[m % T]   (network.py:420-427);
 // the same rows feed the conditional and the unconditional pass.
 struct EpiF32InProj {

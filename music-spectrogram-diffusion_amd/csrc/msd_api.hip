@@ -106,10 +106,16 @@ struct msd_model {
   float* d_coef = nullptr;  // [N][kCoefCount]
   std::vector<float> h_coef;
   float* d_film = nullptr;  // [N][2*Ld][2D]
+  // folded-norm tables (gemm_bf16.h): g = gamma (.) (film_scale + 1); b.W per step
+  float* d_g = nullptr;        // [N][2*Ld][D]
+  float* d_bw_self = nullptr;  // [N][Ld][3J]   film_bias_self . (Wq|Wk|Wv)
+  float* d_bw_mlp = nullptr;   // [N][Ld][2F]   film_bias_mlp  . (wi_0|wi_1), packed column order
 
   // decoder activations (rows = passes*Bmax*T)
   float* x = nullptr;
   Planes h, qk, vt, ao, cq, g;
+  Planes y;                    // x (.) g of the next norm, written by the residual epilogues
+  float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
@@ -130,6 +136,7 @@ struct msd_model {
 
   hipGraphExec_t graph_exec = nullptr;
   int graph_batch = 0;
+  bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
   Profiler prof;
 };
@@ -293,7 +300,7 @@ hipError_t prepare_gemms() {
   hipError_t e = hipSuccess, r;
 #define PREP(WIDE, EPI) if ((r = gemm_bf16_dma_prepare<NP, 64, 64, GemmCfg<NP, WIDE>::NS, EPI>()) != hipSuccess) e = r;
   PREP(true, EpiQKV<NP>) PREP(true, EpiGeglu<NP>)
-  PREP(false, EpiResidual) PREP(false, EpiStoreBf16<NP>) PREP(false, EpiStoreF32)
+  PREP(false, EpiResidual) PREP(false, EpiResidualNorm<NP>) PREP(false, EpiStoreBf16<NP>) PREP(false, EpiStoreF32)
 #undef PREP
   return e;
 }
@@ -471,6 +478,27 @@ int build_tables(msd_model* m, hipStream_t s) {
       gemm32(c, KC_IN_PROJ, d_e1, 4 * D, W(m, name), 2 * D, N, 2 * D, 4 * D,
              EpiF32Store{m->d_film + (size_t)(2 * l + k) * 2 * D, 2 * m->Ld * 2 * D});
     }
+  // folded-norm tables
+  {
+    const int slots = 2 * m->Ld, J = m->J, F = m->F;
+    const int nthreads = N * D;
+    for (int l = 0; l < m->Ld; ++l) {
+      const std::string lp = "decoder/layers_" + std::to_string(l);
+      hipLaunchKernelGGL(build_g_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, m->d_film,
+                         W(m, lp + "/pre_self_attention_layer_norm/scale"), m->d_g, N, slots, 2 * l, D);
+      hipLaunchKernelGGL(build_g_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, m->d_film,
+                         W(m, lp + "/pre_mlp_layer_norm/scale"), m->d_g, N, slots, 2 * l + 1, D);
+      const float* bias_self = m->d_film + (size_t)(2 * l) * 2 * D + D;      // row = step, lda = slots*2D
+      const float* bias_mlp = m->d_film + (size_t)(2 * l + 1) * 2 * D + D;
+      const char* qkv[3] = {"/self_attention/query/kernel", "/self_attention/key/kernel", "/self_attention/value/kernel"};
+      for (int t = 0; t < 3; ++t)
+        gemm32(c, KC_IN_PROJ, bias_self, slots * 2 * D, W(m, lp + qkv[t]), J, N, J, D,
+               EpiF32Store{m->d_bw_self + (size_t)l * 3 * J + t * J, m->Ld * 3 * J});
+      for (int t = 0; t < 2; ++t)
+        gemm32(c, KC_IN_PROJ, bias_mlp, slots * 2 * D, W(m, lp + "/mlp/wi_" + std::to_string(t) + "/kernel"), F, N, F, D,
+               EpiF32StoreGated{m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F, t});
+    }
+  }
   HIP_TRY(m, hipStreamSynchronize(s));
   (void)hipFree(d_sig); (void)hipFree(d_e0); (void)hipFree(d_e1);
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "table build failed: %s", hipGetErrorString(c.err));
@@ -599,15 +627,15 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
 
 // ---- one decoder evaluation (network.py:360-457) on rows [0, P*batch*T) ----------
 // pass 0 is conditional iff `cond0`; pass 1 (if P == 2) is the unconditional CFG pass.
+// Unfolded variant: one RMSNorm(+FiLM) kernel in front of every projection.
 template <int NP>
-void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
+void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
   msd_model* m = c.m;
   const int D = m->D, J = m->J, F = m->F, T = m->T;
   const int BT = batch * T, M = P * BT;
   const int slots = 2 * m->Ld;
   for (int l = 0; l < m->Ld; ++l) {
     const DecLayerW& w = m->dec[l];
-    // (i) self-attention block (network.py:174-193)
     norm<NP>(c, m->x, w.ln_self, M, D, m->d_film, slots, 2 * l, &m->h, nullptr);
     EpiQKV<NP> eq;
     eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
@@ -618,7 +646,6 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
                   (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
     gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
-    // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
       EpiStoreBf16<NP> es;
@@ -633,12 +660,87 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
                     (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
       gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
-    // (iii) MLP block (network.py:241-256)
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
     gemm<NP, true>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
     gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
+  }
+  norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
+  gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
+}
+
+template <int NP>
+void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
+  msd_model* m = c.m;
+  if (!m->fold_norm) { decoder_layers_unfolded<NP>(c, batch, P, cond0); return; }
+  const int D = m->D, J = m->J, F = m->F, T = m->T;
+  const int BT = batch * T, M = P * BT;
+  const int slots = 2 * m->Ld, tiles = D / 64;
+  auto rowscale = [&](const float* bias, int stride) {
+    RowScale r;
+    r.ssq = m->ssq; r.tiles = tiles; r.inv_d = 1.0f / (float)D; r.bias = bias; r.bias_step_stride = stride;
+    r.step_ptr = m->d_step;
+    return r;
+  };
+  auto g_tab = [&](int slot) { return m->d_g + (size_t)slot * D; };  // + step * slots * D in the kernel
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW& w = m->dec[l];
+    // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
+    // through one norm kernel; later layers consume the folded-norm planes `y` written by the
+    // previous layer's MLP output projection.
+    EpiQKV<NP> eq;
+    eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
+    eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
+    eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
+    if (l == 0) {
+      norm<NP>(c, m->x, w.ln_self, M, D, m->d_film, slots, 0, &m->h, nullptr);
+      gemm<NP, true>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    } else {
+      eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
+      gemm<NP, true>(c, KC_GEMM_QKV, m->y, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    }
+    const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
+    attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
+                  (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
+    // out-projection + residual; produces y for the cross-attention norm (conditional rows:
+    // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
+    EpiResidualNorm<NP> er;
+    er.x = m->x; er.ldx = D; er.y[0] = m->y.p[0]; er.y[1] = m->y.p[NP - 1]; er.ssq = m->ssq; er.tiles = tiles;
+    er.step_ptr = m->d_step;
+    er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
+    er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
+    er.split_row = cond0 ? BT : 0;
+    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, er);
+    // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
+    if (cond0) {
+      EpiStoreBf16<NP> es;
+      es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
+      es.rsc = rowscale(nullptr, 0);
+      gemm<NP, false>(c, KC_GEMM_CROSS_Q, m->y, D, w.wq_cross, D, BT, J, D, es);
+      const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
+      const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
+      Planes vt;
+      vt.p[0] = m->vtc.p[0] + loff;
+      vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
+      attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
+                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
+      EpiResidualNorm<NP> ec = er;
+      ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
+      ec.split_row = BT;
+      gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, ec);
+    }
+    // (iii) MLP block (network.py:241-256)
+    EpiGeglu<NP> eg;
+    eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
+    eg.rsc = rowscale(m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F);
+    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->y, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    EpiResidualNorm<NP> eo = er;
+    const bool last = (l + 1 == m->Ld);
+    eo.g_lo = eo.g_hi = last ? nullptr : g_tab(2 * (l + 1));
+    eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
+    eo.split_row = 0;
+    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, eo);
   }
   // decoder_norm + spec_out_dense in fp32 (network.py:445-456)
   norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
@@ -721,6 +823,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->ND = cfg->n_dims; m->N = cfg->num_steps; m->Ld = cfg->num_decoder_layers; m->Le = cfg->num_encoder_layers;
   m->Bmax = cfg->max_batch;
   m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
+  if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
   m->S_pad = round_up(m->L + m->C, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
   declare_weights(m);
@@ -734,7 +837,12 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   for (auto& w : m->weights) TRY(dalloc(m, &w.dev, (size_t)w.numel()));
   TRY(dalloc(m, &m->d_coef, (size_t)m->N * kCoefCount));
   TRY(dalloc(m, &m->d_film, (size_t)m->N * 2 * m->Ld * 2 * D));
+  TRY(dalloc(m, &m->d_g, (size_t)m->N * 2 * m->Ld * D));
+  TRY(dalloc(m, &m->d_bw_self, (size_t)m->N * m->Ld * 3 * J));
+  TRY(dalloc(m, &m->d_bw_mlp, (size_t)m->N * m->Ld * 2 * F));
   TRY(dalloc(m, &m->x, Mmax * D));
+  TRY(palloc(m, &m->y, Mmax * D));
+  TRY(dalloc(m, &m->ssq, Mmax * (D / 64)));
   TRY(palloc(m, &m->h, Mmax * D));
   TRY(palloc(m, &m->qk, Mmax * 2 * J));
   TRY(palloc(m, &m->vt, Mmax * J));

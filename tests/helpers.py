@@ -59,3 +59,23 @@ def rms(a, b):
   a = np.asarray(a, np.float64)
   b = np.asarray(b, np.float64)
   return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def assert_fp32_class(got, ref64, ref32, what=''):
+  """Short DDPM chains are ill-conditioned by construction: at the first step
+  (t = 1, logsnr = -20) x0 = 22026 (z - eps) is clipped to +-1 for all but a few
+  marginal elements, where a 1e-6 difference in eps decides the outcome.  Any two valid
+  float32-class evaluations (the float32 oracle included) therefore disagree on a
+  handful of elements by O(1) while agreeing to ~1e-6 on the rest, and rms is
+  dominated by those few.  So the device is compared with the float64 oracle on the
+  BULK (median error) and on the COUNT of outliers, using the float32 oracle's own
+  deviation from float64 as the yardstick.  (The 1000-step runs use the absolute
+  1e-3 rms bar: tests/test_golden.py.)"""
+  e_dev = np.abs(np.asarray(got, np.float64) - ref64).ravel()
+  e_f32 = np.abs(np.asarray(ref32, np.float64) - ref64).ravel()
+  med_dev, med_f32 = np.median(e_dev), np.median(e_f32)
+  out_dev, out_f32 = float((e_dev > 1e-2).mean()), float((e_f32 > 1e-2).mean())
+  print('%s median |err| device %.2e / f32-oracle %.2e; outliers(>1e-2) device %.4f / f32-oracle %.4f; rms %.2e / %.2e'
+        % (what, med_dev, med_f32, out_dev, out_f32, rms(got, ref64), rms(ref32, ref64)))
+  assert med_dev <= 3 * med_f32 + 2e-6, 'bulk error is not fp32-class'
+  assert out_dev <= 4 * out_f32 + 5e-3, 'too many outliers'
