@@ -345,29 +345,35 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
       MSD_D_ISSUE(kt + NS - 1, nb)   // into the slot compute(kt-1) just released
     }
     const char* base = smem + buf * STAGE_BYTES;
+    // all fragment reads of the K-tile are issued up front (both 32-wide halves); the
+    // MFMAs of the first half then run under the LDS latency of the second half
+    mfma_bf16x8 fa[2][NP][FM], fb[2][NP][FN];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      mfma_bf16x8 fa[NP][FM], fb[NP][FN];
       const int c = kk * 4 + (lane >> 4);
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
-          fa[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(
+          fa[kk][pl][i] = *reinterpret_cast<const mfma_bf16x8*>(
               base + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c));
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          fb[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(
+          fb[kk][pl][j] = *reinterpret_cast<const mfma_bf16x8*>(
               base + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][0][j], fa[kk][0][i], acc[i][j], 0, 0, 0);
           if (NP == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NP - 1][j], fa[0][i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[NP - 1][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][NP - 1][j], fa[kk][0][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][0][j], fa[kk][NP - 1][i], acc[i][j], 0, 0, 0);
           }
         }
     }
@@ -573,12 +579,12 @@ struct EpiResidualNorm {
   const int* step_ptr;
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid) const {
-    static_assert(BN == 64, "partial sums of squares are per 64-column tile");
+    static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile (tiles = D / BN)");
     const int step = *step_ptr;
     const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
     const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
     for (int item = tid; item < BM * BN / 8; item += 256) {
-      const int m = item / 8, n = (item % 8) * 8;   // 8 consecutive lanes share a row
+      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;   // BN/8 consecutive lanes share a row
       float v[8];
       tile_row8<LD>(s0, m, n, v);
       const int row = m0 + m, col = n0 + n;
@@ -593,8 +599,8 @@ struct EpiResidualNorm {
       for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
       sq += __shfl_xor(sq, 1, 64);
       sq += __shfl_xor(sq, 2, 64);
-      sq += __shfl_xor(sq, 4, 64);
-      if ((item & 7) == 0) ssq[(size_t)row * tiles + (n0 >> 6)] = sq;
+      if (BN == 64) sq += __shfl_xor(sq, 4, 64);
+      if ((item % (BN / 8)) == 0) ssq[(size_t)row * tiles + n0 / BN] = sq;
       const float* g = row < split_row ? glo : ghi;
       if (g) {
         const float4 g0 = *reinterpret_cast<const float4*>(g + col);

@@ -280,17 +280,23 @@ GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, 
   return p;
 }
 
-// Kernel selection (gemm_bf16.h; numbers from tools/ubench/gemm_bench.hip, bf16x3): the
-// LDS-DMA variant with 64 x 64 tiles everywhere; a 2-deep ring (64 KiB -> two blocks per
-// CU) for the wide-N projections whose grids exceed the CU count (QKV, gated MLP input),
-// a 3-deep ring (one block per CU, longer prefetch distance) for the N = D projections.
-template <int NP, bool WIDE> struct GemmCfg { static constexpr int NS = (NP == 2 && WIDE) ? 2 : 3; };
+// Kernel selection (gemm_bf16.h; numbers from tools/ubench/gemm_bench.hip, bf16x3).  The
+// LDS-DMA variant everywhere.  Wide-N projections (QKV, gated MLP input: 288..512 blocks):
+// 64 x 64 tiles, 2-deep ring (64 KiB -> two blocks per CU).  N = D projections: at 64 x 64
+// they have 96 blocks and are bound by the per-CU ingest rate (~31 B/clk with one block per
+// CU), so they use 32 x 32 tiles (384 blocks, 4-deep ring, two blocks per CU).
+constexpr int kNarrowTile = 32;
+template <int NP, bool WIDE> struct GemmCfg {
+  static constexpr int BM = WIDE ? 64 : kNarrowTile, BN = WIDE ? 64 : kNarrowTile;
+  static constexpr int NS = WIDE ? ((NP == 2) ? 2 : 3) : 4;
+};
 
 template <int NP, bool WIDE, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi) {
+  typedef GemmCfg<NP, WIDE> G;
   c.begin(kc);
-  hipError_t e = launch_gemm_bf16_dma<NP, 64, 64, GemmCfg<NP, WIDE>::NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
+  hipError_t e = launch_gemm_bf16_dma<NP, G::BM, G::BN, G::NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
@@ -298,10 +304,11 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 template <int NP>
 hipError_t prepare_gemms() {
   hipError_t e = hipSuccess, r;
-#define PREP(WIDE, EPI) if ((r = gemm_bf16_dma_prepare<NP, 64, 64, GemmCfg<NP, WIDE>::NS, EPI>()) != hipSuccess) e = r;
+#define PREP(WIDE, EPI) if ((r = gemm_bf16_dma_prepare<NP, GemmCfg<NP, WIDE>::BM, GemmCfg<NP, WIDE>::BN, GemmCfg<NP, WIDE>::NS, EPI>()) != hipSuccess) e = r;
   PREP(true, EpiQKV<NP>) PREP(true, EpiGeglu<NP>)
-  PREP(false, EpiResidual) PREP(false, EpiResidualNorm<NP>) PREP(false, EpiStoreBf16<NP>) PREP(false, EpiStoreF32)
+  PREP(false, EpiResidual) PREP(false, EpiResidualNorm<NP>) PREP(false, EpiStoreBf16<NP>)
 #undef PREP
+  if ((r = gemm_bf16_dma_prepare<NP, 64, 64, 3, EpiStoreF32>()) != hipSuccess) e = r;
   return e;
 }
 
@@ -676,7 +683,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
   if (!m->fold_norm) { decoder_layers_unfolded<NP>(c, batch, P, cond0); return; }
   const int D = m->D, J = m->J, F = m->F, T = m->T;
   const int BT = batch * T, M = P * BT;
-  const int slots = 2 * m->Ld, tiles = D / 64;
+  const int slots = 2 * m->Ld, tiles = D / kNarrowTile;
   auto rowscale = [&](const float* bias, int stride) {
     RowScale r;
     r.ssq = m->ssq; r.tiles = tiles; r.inv_d = 1.0f / (float)D; r.bias = bias; r.bias_step_stride = stride;
@@ -842,7 +849,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_bw_mlp, (size_t)m->N * m->Ld * 2 * F));
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
-  TRY(dalloc(m, &m->ssq, Mmax * (D / 64)));
+  TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   TRY(palloc(m, &m->h, Mmax * D));
   TRY(palloc(m, &m->qk, Mmax * 2 * J));
   TRY(palloc(m, &m->vt, Mmax * J));

@@ -54,6 +54,11 @@ int main() {
       double d5 = run<1, 128, 128, 3, true>(s.M, s.N, s.K, 200, s.resid);
       printf("   DMA     bf16x3: 64x64 NS3 %6.1f us (%5.1f TF) NS2 %6.1f | 128x64 NS3 %6.1f us || bf16: 64x64 NS4 %6.1f us | 128x128 NS3 %6.1f\n",
              d1, gf / d1 * 1e-3, d2, d3, d4, d5);
+      double e1 = run<2, 32, 64, 3, true>(s.M, s.N, s.K, 200, s.resid);
+      double e2 = run<2, 32, 64, 4, true>(s.M, s.N, s.K, 200, s.resid);
+      double e3 = run<2, 64, 32, 3, true>(s.M, s.N, s.K, 200, s.resid);
+      double e4 = run<2, 32, 32, 4, true>(s.M, s.N, s.K, 200, s.resid);
+      printf("   DMA     bf16x3: 32x64 NS3 %6.1f NS4 %6.1f | 64x32 NS3 %6.1f | 32x32 NS4 %6.1f\n", e1, e2, e3, e4);
     }
   }
   return 0;
