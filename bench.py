@@ -65,12 +65,12 @@ def class_flops(spec, s_valid: float, passes: int):
   }
 
 
-def cpu_baseline(spec, params, batch, sample_steps: int):
+def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0):
   """Oracle ('port') on the host cores: encoders once + `sample_steps` DDPM steps."""
   import torch
   from oracle import backend, fast
   from tests import helpers
-  cores = os.cpu_count() or 1
+  cores = backend.effective_cpus()
   xp = backend.TorchBackend('float32', threads=cores)
   cfg, dc = helpers.oracle_configs(spec)
   n_full = dc.sampler.schedule.num_steps
@@ -88,12 +88,17 @@ def cpu_baseline(spec, params, batch, sample_steps: int):
   w = dc.classifier_free_guidance.eval_condition_weight
   fm.decoder_pass(z, n_full - 1, True)  # warm the weight caches
   t0 = time.perf_counter()
+  done = 0
   for k in range(sample_steps):
     i = n_full - 1 - k
     e = fm.decoder_pass(z, i, True)
     if w != 1:
       e = w * e + (1 - w) * fm.decoder_pass(z, i, False)
     z = z * 0.999 + 0.001 * e  # keep the data flowing; the sampler update is negligible
+    done += 1
+    if time.perf_counter() - t0 > budget_s:  # bounded sample: stop after ~budget_s of CPU work
+      break
+  sample_steps = done
   t_step = (time.perf_counter() - t0) / sample_steps
   seg_s = t_enc + n_full * t_step
   return {

@@ -43,6 +43,13 @@ struct AttnParams {
   size_t k_seg_stride;  // elements between segments of k
   size_t vt_seg_stride; // elements between segments of vt
   int k_rows;           // allocated key rows per segment (DMA source rows are clamped to it)
+  // key split across blocks (cross-attention: more CUs for the long key axis).  ksplit > 1:
+  // block (q-group, ks) takes stages ks, ks+ksplit, ... and writes its un-normalised partial
+  // (O relative to its own max m, and m, l) to the workspace; attention_merge_kernel finishes.
+  int ksplit;
+  float* part_o;        // [ksplit][rows][heads*64]
+  float* part_ml;       // [ksplit][rows][heads][2]
+  int total_rows;       // rows of q over all segments
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag8;
@@ -79,10 +86,13 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wave / kAttKG, kg = wave % kAttKG;
-  const int blk = blockIdx.x, head = blockIdx.y, seg = blockIdx.z;
+  const int blk = blockIdx.x / p.ksplit, ks = blockIdx.x % p.ksplit;
+  const int head = blockIdx.y, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
   const int nkeys = p.n_keys[seg];
-  const int nst = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
+  const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
+  // this block's stages: global stage index = ks + i * ksplit, i = 0..nst-1
+  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) / p.ksplit : 0;
 
   // ---- DMA source addressing -------------------------------------------------------
   // K tile: instruction j (0..15) moves keys 8j..8j+7 of the stage, lane = (r = lane>>3, c' = lane&7),
@@ -105,7 +115,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
 #define MSD_A_ISSUE(ST, BUF)                                                                      \
   {                                                                                               \
     char* base_ = smem + (BUF) * STAGE;                                                           \
-    const int kb_ = (ST) * kAttStageKeys;                                                         \
+    const int kb_ = (ks + (ST) * p.ksplit) * kAttStageKeys;                                       \
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                           \
       _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                          \
         const int j_ = 2 * wave + jj;                                                             \
@@ -155,7 +165,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
       if (nb >= NS) nb -= NS;
       MSD_A_ISSUE(st + NS - 1, nb)
     }
-    const int kb0 = st * kAttStageKeys + kg * 32;  // first key of this wave's block
+    const int kb0 = (ks + st * p.ksplit) * kAttStageKeys + kg * 32;  // first key of this wave's block
     if (kb0 < nkeys) {
       const char* kt = smem + buf * STAGE;
       const char* vt = kt + NP * kAttKBytes;
@@ -292,13 +302,53 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
       acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
       acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
     }
-    const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
-    const size_t off = ((size_t)seg * p.q_rows_per_seg + blk * 64 + mqb * 32 + q) * p.ldo + head * 64 + d0;
-    float v[8];
+    const size_t row = (size_t)seg * p.q_rows_per_seg + blk * 64 + mqb * 32 + q;
+    if (p.ksplit == 1) {
+      const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
-    store_bf16x8<NP>(p.o, off, v);
+      for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+      store_bf16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v);
+    } else {
+      const int heads = gridDim.y;
+      float* po = p.part_o + (((size_t)ks * p.total_rows + row) * heads + head) * 64 + d0;
+      *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(po + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      if (d0 == 0) {
+        float* pm = p.part_ml + (((size_t)ks * p.total_rows + row) * heads + head) * 2;
+        pm[0] = mt;
+        pm[1] = lt;
+      }
+    }
   }
+}
+
+// Finish a key-split attention: out[row][head*64 + d] = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m)
+template <int NP>
+__global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int heads) {
+  const int item = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d group)
+  const int d0 = (item & 7) * 8, head = (item >> 3) % heads, row = (item >> 3) / heads;
+  if (row >= p.total_rows) return;
+  float mt = -1e30f;
+  for (int ks = 0; ks < p.ksplit; ++ks)
+    mt = fmaxf(mt, p.part_ml[(((size_t)ks * p.total_rows + row) * heads + head) * 2]);
+  float lt = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int ks = 0; ks < p.ksplit; ++ks) {
+    const size_t base = ((size_t)ks * p.total_rows + row) * heads + head;
+    const float f = fast_exp(p.part_ml[base * 2] - mt);
+    lt += p.part_ml[base * 2 + 1] * f;
+    const float4 a = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0);
+    const float4 b = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0 + 4);
+    acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
+    acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
+  }
+  const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+  store_bf16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v);
 }
 
 template <int NP, int NS>
@@ -316,8 +366,12 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   constexpr int smem = attention_smem<NP, NS>();
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3(p.q_rows_per_seg / 64, heads, segs),
+  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3((p.q_rows_per_seg / 64) * p.ksplit, heads, segs),
                      dim3(kAttWaves * 64), smem, stream, p);
+  if (p.ksplit > 1) {
+    const int items = p.total_rows * heads * 8;
+    hipLaunchKernelGGL((attention_merge_kernel<NP>), dim3((items + 255) / 256), dim3(256), 0, stream, p, heads);
+  }
   return hipGetLastError();
 }
 

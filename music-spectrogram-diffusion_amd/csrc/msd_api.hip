@@ -116,6 +116,8 @@ struct msd_model {
   Planes h, qk, vt, ao, cq, g;
   Planes y;                    // x (.) g of the next norm, written by the residual epilogues
   float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
+  float *att_part_o = nullptr, *att_part_ml = nullptr;  // key-split attention partials
+  int cross_ksplit = 1;
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
@@ -340,7 +342,7 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs) {
+               int segs, int ksplit = 1) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -349,6 +351,8 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2
   p.n_keys = n_keys; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
   p.q_rows_per_seg = q_rows_per_seg; p.k_seg_stride = k_seg_stride;
   p.vt_seg_stride = vt_seg_stride; p.k_rows = k_rows;
+  p.ksplit = ksplit; p.part_o = c.m->att_part_o; p.part_ml = c.m->att_part_ml;
+  p.total_rows = q_rows_per_seg * segs;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -664,7 +668,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       vt.p[0] = m->vtc.p[0] + loff;
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
-                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
+                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
       gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
@@ -731,7 +735,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
       vt.p[0] = m->vtc.p[0] + loff;
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
-                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch);
+                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
       EpiResidualNorm<NP> ec = er;
       ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
       ec.split_row = BT;
@@ -850,6 +854,11 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
+  // cross-attention key split: enough blocks for the whole chip when the key axis is long
+  m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
+  if (const char* v = getenv("MSD_CROSS_KSPLIT")) m->cross_ksplit = atoi(v) > 0 ? atoi(v) : 1;
+  TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
+  TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
   TRY(palloc(m, &m->h, Mmax * D));
   TRY(palloc(m, &m->qk, Mmax * 2 * J));
   TRY(palloc(m, &m->vt, Mmax * J));
@@ -1280,6 +1289,15 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   }
   p.n_keys = d_nk; p.ldq = J; p.ldk = J; p.ldo = J; p.vt_ld = n_keys; p.q_rows_per_seg = n_q;
   p.k_seg_stride = 0; p.vt_seg_stride = 0; p.k_rows = n_keys;
+  p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr; p.total_rows = n_q;
+  float *po = nullptr, *pml = nullptr;
+  if (n_keys >= 512) {  // exercise the key-split path + merge kernel on long key axes
+    p.ksplit = 3;
+    po = sc.get<float>((size_t)3 * n_q * J);
+    pml = sc.get<float>((size_t)3 * n_q * heads * 2);
+    if (!po || !pml) return MSD_ERR_HIP;
+    p.part_o = po; p.part_ml = pml;
+  }
   hipError_t e = NP == 2 ? launch_attention<2>(p, heads, 1, s) : launch_attention<1>(p, heads, 1, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,

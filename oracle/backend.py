@@ -12,6 +12,26 @@ from __future__ import annotations
 import numpy as np
 
 
+def effective_cpus() -> int:
+  """CPUs this process may actually use: min(affinity mask, cgroup v2/v1 quota).  (The GPU
+  box shows 256 logical CPUs under a 16-CPU quota; 256 torch threads there never finish.)"""
+  import os
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+    if q != 'max':
+      n = min(n, max(1, int(int(q) / int(p))))
+  except Exception:
+    try:
+      q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+      p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+      if q > 0:
+        n = min(n, max(1, q // p))
+    except Exception:
+      pass
+  return max(1, n)
+
+
 class NumpyBackend:
   name = 'numpy'
 
@@ -116,8 +136,7 @@ class TorchBackend:
   def __init__(self, dtype='float32', threads=None):
     import torch  # local import: torch is plumbing for the fast CPU leg only
     self.t = torch
-    if threads:
-      torch.set_num_threads(int(threads))
+    torch.set_num_threads(int(threads) if threads else effective_cpus())
     self.dtype = {'float32': torch.float32, 'float64': torch.float64}[
         str(np.dtype(dtype))]
     t = torch

@@ -6,7 +6,7 @@
 #include "../../music-spectrogram-diffusion_amd/csrc/attention.h"
 using namespace msd;
 
-template <int NP>
+template <int NP, int KS = 1>
 double run(int segs, int heads, int nq, int nkeys, int kpad, int iters) {
   const int J = heads * 64;
   AttnParams p; int* nk; hipMalloc(&nk, segs * 4);
@@ -21,6 +21,8 @@ double run(int segs, int heads, int nq, int nkeys, int kpad, int iters) {
   }
   p.n_keys = nk; p.ldq = J; p.ldk = J; p.ldo = J; p.vt_ld = kpad; p.q_rows_per_seg = nq;
   p.k_seg_stride = (size_t)kpad * J; p.vt_seg_stride = (size_t)J * kpad; p.k_rows = kpad;
+  p.ksplit = KS; p.total_rows = segs * nq;
+  hipMalloc(&p.part_o, (size_t)KS * segs * nq * J * 4); hipMalloc(&p.part_ml, (size_t)KS * segs * nq * heads * 8);
   for (int i = 0; i < 3; ++i) launch_attention<NP>(p, heads, segs, 0);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -34,5 +36,8 @@ int main() {
   printf("self  2x12 heads 256x256     : bf16x3 %6.1f us | bf16 %6.1f us\n", run<2>(2, 12, 256, 256, 256, 200), run<1>(2, 12, 256, 256, 256, 200));
   printf("cross 1x12 heads 256x1344    : bf16x3 %6.1f us | bf16 %6.1f us\n", run<2>(1, 12, 256, 1344, 2304, 200), run<1>(1, 12, 256, 1344, 2304, 200));
   printf("cross 1x12 heads 256x2304    : bf16x3 %6.1f us | bf16 %6.1f us\n", run<2>(1, 12, 256, 2304, 2304, 200), run<1>(1, 12, 256, 2304, 2304, 200));
+  printf("cross 256x1344 ksplit 2/3/4/6: bf16x3 %6.1f %6.1f %6.1f %6.1f us\n", run<2, 2>(1, 12, 256, 1344, 2304, 200), run<2, 3>(1, 12, 256, 1344, 2304, 200), run<2, 4>(1, 12, 256, 1344, 2304, 200), run<2, 6>(1, 12, 256, 1344, 2304, 200));
+  printf("cross 256x2304 ksplit 2/3/4/6: bf16x3 %6.1f %6.1f %6.1f %6.1f us\n", run<2, 2>(1, 12, 256, 2304, 2304, 200), run<2, 3>(1, 12, 256, 2304, 2304, 200), run<2, 4>(1, 12, 256, 2304, 2304, 200), run<2, 6>(1, 12, 256, 2304, 2304, 200));
+  printf("self  256x256  ksplit 2      : bf16x3 %6.1f us\n", run<2, 2>(2, 12, 256, 256, 256, 200));
   return 0;
 }
