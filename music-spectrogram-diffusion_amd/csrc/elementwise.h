@@ -98,6 +98,8 @@ struct SamplerParams {
   int passes;           // 2 with CFG
   float cond_wt;        // eval_condition_weight
   int clip_x0, ddim;
+  bf16_t* z_hi;         // optional bf16 planes of the new z (A operand of the next input projection)
+  bf16_t* z_lo;
 };
 
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
@@ -128,6 +130,13 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
       out[k] = (i == 0) ? x0 : zs;
     }
     *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
+    if (p.z_hi) {
+      bf16_t h[4], l[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) split_bf16(out[k], h[k], l[k]);
+      *reinterpret_cast<uint2*>(p.z_hi + idx) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      if (p.z_lo) *reinterpret_cast<uint2*>(p.z_lo + idx) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+    }
   }
   // every block has read *step_ptr before any kernel of the next step can start
   // (kernel boundary); the decrement is ordered by the same boundary.

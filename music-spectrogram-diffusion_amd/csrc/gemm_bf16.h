@@ -613,16 +613,73 @@ struct EpiResidualNorm {
   }
 };
 
-// out fp32 [M, ldc] = acc
-struct EpiStoreF32 {
-  float* out;
-  int ldc;
+// Decoder input (network.py:420-427): x[pass][m][:] = z[m] . W_in + pos[m % T] for every
+// pass (the conditional and the unconditional CFG pass start from the same rows), plus
+// the folded-norm inputs of layer 0's self-attention projection (y = x (.) g, ssq).
+template <int NP>
+struct EpiInProj {
+  float* x;
+  int ldx;
+  const float* pos;
+  int T, pass_rows, passes;
+  bf16_t* y[2];
+  float* ssq;
+  int tiles;
+  const float* g; int g_stride;
+  const int* step_ptr;
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid) const {
+    static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile");
+    const float* gs = g + (size_t)(*step_ptr) * g_stride;
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
       tile_row8<LD>(s0, m, n, v);
+      const int row = m0 + m, col = n0 + n;
+      const float4 p0 = *reinterpret_cast<const float4*>(pos + (size_t)(row % T) * ldx + col);
+      const float4 p1 = *reinterpret_cast<const float4*>(pos + (size_t)(row % T) * ldx + col + 4);
+      v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+      v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      if (BN == 64) sq += __shfl_xor(sq, 4, 64);
+      const float4 g0 = *reinterpret_cast<const float4*>(gs + col);
+      const float4 g1 = *reinterpret_cast<const float4*>(gs + col + 4);
+      float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w,
+                    v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
+      for (int ps = 0; ps < passes; ++ps) {
+        const size_t r = (size_t)ps * pass_rows + row;
+        float4* px = reinterpret_cast<float4*>(x + r * ldx + col);
+        px[0] = make_float4(v[0], v[1], v[2], v[3]);
+        px[1] = make_float4(v[4], v[5], v[6], v[7]);
+        if ((item % (BN / 8)) == 0) ssq[r * tiles + n0 / BN] = sq;
+        store_bf16x8<NP>(y, r * ldx + col, w);
+      }
+    }
+  }
+};
+
+// out fp32 [M, ldc] = acc [* rstd[m] + bias[n]]
+struct EpiStoreF32 {
+  float* out;
+  int ldc;
+  RowScale rsc;
+  template <int BM, int BN, int LD>
+  __device__ void run(float* s0, int m0, int n0, int tid) const {
+    float* rs = s0 + BM * LD;
+    const float* bias = nullptr;
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
+    for (int item = tid; item < BM * BN / 8; item += 256) {
+      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+      float v[8];
+      tile_row8<LD>(s0, m, n, v);
+      if (rsc.ssq) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+      }
       float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
       po[0] = make_float4(v[0], v[1], v[2], v[3]);
       po[1] = make_float4(v[4], v[5], v[6], v[7]);
