@@ -119,6 +119,82 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Params p, Epi epi)
       }
 }
 
+// ----------------------------------------------------------------------------
+// Final projection of the decoder in exact fp32 (network.py:445-456), folded with the
+// decoder_norm:  eps[m][n] = rstd[m] * sum_k x[m][k] * (gamma[k] W[k][n]).
+// M = 512, N = 128, K = 768 is 0.1 GFLOP: tiny, so the 4 waves of a block split K
+// (wave w takes the 16-wide K groups w, w+4, ...) on one 32 x 32 tile, 64 blocks.
+// v_mfma_f32_16x16x4_f32 operand k = lane>>4; a lane loads float4 x[row][k0 + 4g .. +3]
+// (g = lane>>4) and uses component c in MFMA c, so MFMA c contracts k = k0 + 4g + c; the
+// B operand of MFMA c is the matching row Wg[k0 + 4g + c][n].
+// ----------------------------------------------------------------------------
+struct FinalProjParams {
+  const float* x;      // [M, K] fp32 residual stream
+  const float* wg;     // [K, N] = diag(gamma) . W
+  const float* ssq;    // [M][tiles] partial sums of squares of x
+  float* out;          // [M, N]
+  int M, N, K, tiles;
+  float inv_d;
+};
+
+__global__ void __launch_bounds__(256) final_proj_f32_kernel(FinalProjParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4][32][33];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nbn = p.N / 32;
+  const int m0 = (blockIdx.x / nbn) * 32, n0 = (blockIdx.x % nbn) * 32;
+  const int g = lane >> 4, r = lane & 15;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xa = p.x + (size_t)(m0 + r) * p.K + 4 * g;
+  const float* wb = p.wg + (size_t)(4 * g) * p.N + n0 + r;
+  for (int k0 = wave * 16; k0 < p.K; k0 += 64) {
+    float4 a[2];
+    float b[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + k0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[j][c] = wb[(size_t)(k0 + c) * p.N + j * 16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float av = c == 0 ? a[i].x : (c == 1 ? a[i].y : (c == 2 ? a[i].z : a[i].w));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][c], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // C layout: col = lane & 15, row = (lane >> 4) * 4 + e
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][i * 16 + g * 4 + e][j * 16 + r] = acc[i][j][e];
+  __syncthreads();
+  for (int item = threadIdx.x; item < 32 * 32; item += 256) {
+    const int m = item >> 5, n = item & 31;
+    const float v = red[0][m][n] + red[1][m][n] + red[2][m][n] + red[3][m][n];
+    const float* q = p.ssq + (size_t)(m0 + m) * p.tiles;
+    float ss = 0.f;
+    for (int t = 0; t < p.tiles; ++t) ss += q[t];
+    p.out[(size_t)(m0 + m) * p.N + n0 + n] = v * (1.0f / sqrtf(ss * p.inv_d + 1e-6f));
+  }
+}
+
+// wg[k][n] = gamma[k] * w[k][n]
+__global__ void scale_rows_kernel(const float* w, const float* gamma, float* wg, int K, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < K * N) wg[i] = gamma[i / N] * w[i];
+}
+
 template <class Epi>
 inline hipError_t launch_gemm_f32(const GemmF32Params& p, const Epi& epi, hipStream_t stream) {
   const int grid = ((p.M + 63) / 64) * (p.N / 64);

@@ -116,6 +116,7 @@ struct msd_model {
   Planes h, qk, vt, ao, cq, g;
   Planes y;                    // x (.) g of the next norm, written by the residual epilogues
   Planes zp;                   // bf16 planes of z (A operand of the folded input projection)
+  float* w_out_g = nullptr;    // diag(decoder_norm scale) . spec_out_dense, fp32 [D][n]
   Planes w_in_p, w_out_p;      // packed W^T of continuous_inputs_projection [D][n] / spec_out_dense [n][D]
   float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
   float *att_part_o = nullptr, *att_part_ml = nullptr;  // key-split attention partials
@@ -757,8 +758,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
   // parity tests show 40x more clip-boundary outliers.  Parity mode therefore runs it on the
   // exact-fp32 MFMA; the plain bf16 mode uses the folded bf16 GEMM like its other layers.
   if (NP == 2) {
-    norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
-    gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
+    FinalProjParams fp;
+    fp.x = m->x; fp.wg = m->w_out_g; fp.ssq = m->ssq; fp.out = m->eps;
+    fp.M = M; fp.N = m->ND; fp.K = D; fp.tiles = tiles; fp.inv_d = 1.0f / (float)D;
+    c.begin(KC_FINAL_PROJ);
+    hipLaunchKernelGGL(final_proj_f32_kernel, dim3((M / 32) * (m->ND / 32)), dim3(256), 0, c.s, fp);
+    c.end(KC_FINAL_PROJ);
   } else {
     EpiStoreF32 ef;
     ef.out = m->eps; ef.ldc = m->ND; ef.rsc = rowscale(nullptr, 0);
@@ -1008,6 +1013,9 @@ int msd_finalize_weights(msd_model* m, void* stream) {
   if ((rc = palloc(m, &m->w_out_p, (size_t)m->ND * D))) return rc;
   if ((rc = pack(m, s, m->w_in_proj, m->ND, D, m->w_in_p, 0, 0))) return rc;
   if ((rc = pack(m, s, m->w_spec_out, D, m->ND, m->w_out_p, 0, 0))) return rc;
+  if ((rc = dalloc(m, &m->w_out_g, (size_t)D * m->ND))) return rc;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((D * m->ND + 255) / 256), dim3(256), 0, s, m->w_spec_out,
+                     m->dec_final_ln, m->w_out_g, D, m->ND);
   if ((rc = build_tables(m, s))) return rc;
   HIP_TRY(m, hipStreamSynchronize(s));
   m->finalized = true;
