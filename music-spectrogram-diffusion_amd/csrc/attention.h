@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wave / kAttKG, kg = wave % kAttKG;
-  const int blk = blockIdx.x / p.ksplit, ks = blockIdx.x % p.ksplit;
-  const int head = blockIdx.y, seg = blockIdx.z;
+  // head is the fastest grid axis: the blocks that share one head's K/V land on few XCDs
+  const int blk = blockIdx.y / p.ksplit, ks = blockIdx.y % p.ksplit;
+  const int head = blockIdx.x, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
   const int nkeys = p.n_keys[seg];
   const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
       for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
       store_bf16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v);
     } else {
-      const int heads = gridDim.y;
+      const int heads = gridDim.x;
       float* po = p.part_o + (((size_t)ks * p.total_rows + row) * heads + head) * 64 + d0;
       *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       *reinterpret_cast<float4*>(po + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -366,7 +367,7 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   constexpr int smem = attention_smem<NP, NS>();
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3((p.q_rows_per_seg / 64) * p.ksplit, heads, segs),
+  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs),
                      dim3(kAttWaves * 64), smem, stream, p);
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;

@@ -275,19 +275,13 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
+  // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
+  // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
   const int nbm = p.M / BM, nbn = p.N / BN;
-  int bm, bn;
-  {
-    const int b = blockIdx.x;
-    if ((nbn & 7) == 0) {
-      const int xcd = b & 7, t = b >> 3;
-      bm = t % nbm;
-      bn = (t / nbm) * 8 + xcd;
-    } else {
-      bm = b % nbm;
-      bn = b / nbm;
-    }
-  }
+  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
+  const int bm = tt % nbm, bn = (tt / nbm) * 8 + xcd;
+  if (bn >= nbn) return;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
@@ -764,7 +758,7 @@ inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipS
   constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
   static const hipError_t attr = gemm_bf16_dma_prepare<NP, BM, BN, NS, Epi>();
   if (attr != hipSuccess) return attr;
-  const int grid = (p.M / BM) * (p.N / BN);
+  const int grid = 8 * ((p.N / BN + 7) / 8) * (p.M / BM);
   hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
 }

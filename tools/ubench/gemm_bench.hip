@@ -32,6 +32,30 @@ double run(int M, int N, int K, int iters, bool resid) {
   return ms * 1e3 / iters;
 }
 
+// same GEMM, but every launch reads a DIFFERENT copy of the weights (COPIES * bytes > L2 + MALL):
+// what a step sees, where each weight matrix is touched once per ~1.4 ms.
+template <int NP, int BM, int BN, int NS>
+double run_cold(int M, int N, int K, int iters, bool resid) {
+  const int COPIES = 48;
+  bf16_t *a[2], *b[2]; float* c; bf16_t* o[2];
+  for (int i = 0; i < 2; ++i) { hipMalloc(&a[i], (size_t)M * K * 2); hipMalloc(&b[i], (size_t)COPIES * N * K * 2); hipMalloc(&o[i], (size_t)M * N * 2);
+    hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)COPIES * N * K * 2); }
+  hipMalloc(&c, (size_t)M * N * 4); hipMemset(c, 0, (size_t)M * N * 4);
+  GemmParams p; for (int i = 0; i < 2; ++i) p.A[i] = a[i]; p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
+  EpiResidual er{c, N}; EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto go = [&](int it) {
+    for (int i = 0; i < 2; ++i) p.B[i] = b[i] + (size_t)(it % COPIES) * N * K;
+    if (resid) launch_gemm_bf16_dma<NP, BM, BN, NS>(p, er, 0); else launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0);
+  };
+  for (int i = 0; i < 5; ++i) go(i);
+  hipDeviceSynchronize();
+  hipEventRecord(e0); for (int i = 0; i < iters; ++i) go(i + 5); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  for (int i = 0; i < 2; ++i) { hipFree(a[i]); hipFree(b[i]); hipFree(o[i]); } hipFree(c);
+  return ms * 1e3 / iters;
+}
+
 int main() {
   struct S { const char* name; int M, N, K; bool resid; } shapes[] = {
       {"qkv      512x2304x768 ", 512, 2304, 768, false}, {"attn_out 512x768x768  ", 512, 768, 768, true},
@@ -59,6 +83,8 @@ int main() {
       double e3 = run<2, 64, 32, 3, true>(s.M, s.N, s.K, 200, s.resid);
       double e4 = run<2, 32, 32, 4, true>(s.M, s.N, s.K, 200, s.resid);
       printf("   DMA     bf16x3: 32x64 NS3 %6.1f NS4 %6.1f | 64x32 NS3 %6.1f | 32x32 NS4 %6.1f\n", e1, e2, e3, e4);
+      printf("   COLD weights (48 copies): 64x64 NS2 %6.1f | 32x32 NS4 %6.1f\n", run_cold<2, 64, 64, 2>(s.M, s.N, s.K, 192, s.resid),
+             run_cold<2, 32, 32, 4>(s.M, s.N, s.K, 192, s.resid));
     }
   }
   return 0;
