@@ -285,36 +285,63 @@ GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, 
   return p;
 }
 
-// Kernel selection (gemm_bf16.h; numbers from tools/ubench/gemm_bench.hip, bf16x3).  The
-// LDS-DMA variant everywhere.  Wide-N projections (QKV, gated MLP input: 288..512 blocks):
-// 64 x 64 tiles, 2-deep ring (64 KiB -> two blocks per CU).  N = D projections: at 64 x 64
-// they have 96 blocks and are bound by the per-CU ingest rate (~31 B/clk with one block per
-// CU), so they use 32 x 32 tiles (384 blocks, 4-deep ring, two blocks per CU).
-constexpr int kNarrowTile = 32;
-template <int NP, bool WIDE> struct GemmCfg {
-  static constexpr int BM = WIDE ? 64 : kNarrowTile, BN = WIDE ? 64 : kNarrowTile;
-  static constexpr int NS = WIDE ? ((NP == 2) ? 2 : 3) : 4;
-};
+// Kernel selection (gemm_bf16.h).  The LDS-DMA variant everywhere; tile shapes from
+// tools/ubench/gemm_bench.hip run with COLD weights (48 rotating copies), which is what a DDPM
+// step sees: every weight matrix is touched once per ~1.4 ms and comes from HBM, so the ring
+// depth has to cover HBM latency, not L2 latency.  bf16x3, M = 512, us warm -> cold:
+//   QKV     N=2304 K=768 : 64x64 NS2 14.0 -> 16.6 | 64x96  NS3 (192 blocks, 1/CU) 11.2 -> 12.7
+//   MLP in  N=4096 K=768 : 64x64 NS2 14.4 -> 17.3 | 64x128 NS3 (256 blocks, 1/CU)      -> 16.2
+//   MLP out N=768 K=2048 : 32x32 NS4      -> 17.6 | 64x32  NS4 (192 blocks)             -> 15.4
+//   N = D, K = D (attention out, cross q/out): 32x32 NS4 (384 blocks, two per CU) 5.2 .. 6.8
+// At 64 x 64 the N = D projections have 96 blocks and are bound by the per-CU ingest rate
+// (~31 B/clk with one block per CU), hence the small tiles there.
+constexpr int kNarrowTile = 32;  // BN of every GEMM that feeds the folded-norm ssq partials
+enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3 };
 
-template <int NP, bool WIDE, class Epi>
-void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
-          const Epi& epi) {
-  typedef GemmCfg<NP, WIDE> G;
+template <int NP, int BM, int BN, int NS, class Epi>
+void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
+            const Epi& epi) {
   c.begin(kc);
-  hipError_t e = launch_gemm_bf16_dma<NP, G::BM, G::BN, G::NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
+  hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
+}
+
+constexpr int wide_ns(int np) { return np == 2 ? 2 : 3; }
+
+// `align` = the largest column granularity the epilogue tolerates besides N itself (QKV: the
+// V^T region must start on a tile boundary).
+template <int NP, int TK, class Epi>
+void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
+          const Epi& epi, int align = 0) {
+  if constexpr (TK == TK_QKV) {
+    if (NP == 2 && N % 96 == 0 && align % 96 == 0)
+      return gemm_t<NP, 64, 96, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+  }
+  else if constexpr (TK == TK_MLP_IN) {
+    if (NP == 2 && N % 128 == 0)
+      return gemm_t<NP, 64, 128, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+  }
+  else {
+    if (TK == TK_TALL && M % 64 == 0)
+      return gemm_t<NP, 64, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    return gemm_t<NP, kNarrowTile, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+  }
 }
 
 template <int NP>
 hipError_t prepare_gemms() {
   hipError_t e = hipSuccess, r;
-#define PREP(WIDE, EPI) if ((r = gemm_bf16_dma_prepare<NP, GemmCfg<NP, WIDE>::BM, GemmCfg<NP, WIDE>::BN, GemmCfg<NP, WIDE>::NS, EPI>()) != hipSuccess) e = r;
-  PREP(true, EpiQKV<NP>) PREP(true, EpiGeglu<NP>)
-  PREP(false, EpiResidual) PREP(false, EpiResidualNorm<NP>) PREP(false, EpiStoreBf16<NP>)
-  PREP(false, EpiStoreF32) PREP(false, EpiInProj<NP>)
+#define PREP(BM, BN, NS, EPI) if ((r = gemm_bf16_dma_prepare<NP, BM, BN, NS, EPI>()) != hipSuccess) e = r;
+  PREP(64, 64, wide_ns(NP), EpiQKV<NP>) PREP(64, 64, wide_ns(NP), EpiGeglu<NP>)
+  if (NP == 2) { PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>) }
+  PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreBf16<NP>)
+  PREP(32, 32, 4, EpiStoreF32) PREP(32, 32, 4, EpiInProj<NP>)
+  PREP(64, 32, 4, EpiResidual) PREP(64, 32, 4, EpiResidualNorm<NP>)
+  PREP(64, 64, 3, EpiStoreF32)
 #undef PREP
-  if ((r = gemm_bf16_dma_prepare<NP, 64, 64, 3, EpiStoreF32>()) != hipSuccess) e = r;
   return e;
 }
 
@@ -532,16 +559,16 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     eq.qk[0] = m->eqk.p[0]; eq.qk[1] = m->eqk.p[NP - 1];
     eq.vt[0] = m->evt.p[0]; eq.vt[1] = m->evt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = m->Lenc_pad; eq.vt_ld = m->Lenc_pad; eq.vt_rows = J;
-    gemm<NP, true>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq);
+    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq, eq.v_start);
     const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->Lenc_pad, m->evt, m->Lenc_pad, 0, m->eao, J,
                   m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
-    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
+    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
     norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->eg.p[0]; eg.out[1] = m->eg.p[NP - 1]; eg.ldc = F;
-    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->eh, D, lw.mlp.wi, D, rows, 2 * F, D, eg);
-    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->eg, F, lw.mlp.wo, F, rows, D, F, EpiResidual{m->ex, D});
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, m->eh, D, lw.mlp.wi, D, rows, 2 * F, D, eg);
+    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, m->eg, F, lw.mlp.wo, F, rows, D, F, EpiResidual{m->ex, D});
   }
 }
 
@@ -629,7 +656,7 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
       ek.qk[0] = m->kc.p[0] + koff; ek.qk[1] = m->kc.p[NP - 1] + koff;
       ek.vt[0] = m->vtc.p[0] + koff; ek.vt[1] = m->vtc.p[NP - 1] + koff;
       ek.ld_qk = J; ek.v_start = J; ek.seg_len = m->S_pad; ek.vt_ld = m->S_pad; ek.vt_rows = J;
-      gemm<NP, true>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek);
+      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek, ek.v_start);
     }
     m->h_nkeys_cross[b] = Sv;
   }
@@ -656,16 +683,16 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
     eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
     eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
-    gemm<NP, true>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
     const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
                   (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
-    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
+    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
     if (cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
-      gemm<NP, false>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -673,13 +700,13 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
                     (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
-      gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
-    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
-    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
   }
   norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
   gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
@@ -709,7 +736,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
     eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
-    gemm<NP, true>(c, KC_GEMM_QKV, m->y, D, w.self.wqkv, D, M, 3 * J, D, eq);
+    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
     const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
                   (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
@@ -721,13 +748,13 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    gemm<NP, false>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, er);
+    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
       es.rsc = rowscale(nullptr, 0);
-      gemm<NP, false>(c, KC_GEMM_CROSS_Q, m->y, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, m->y, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -738,19 +765,19 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
       EpiResidualNorm<NP> ec = er;
       ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
       ec.split_row = BT;
-      gemm<NP, false>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, ec);
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, ec);
     }
     // (iii) MLP block (network.py:241-256)
     EpiGeglu<NP> eg;
     eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
     eg.rsc = rowscale(m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F);
-    gemm<NP, true>(c, KC_GEMM_MLP_IN, m->y, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, m->y, D, w.mlp.wi, D, M, 2 * F, D, eg);
     EpiResidualNorm<NP> eo = er;
     const bool last = (l + 1 == m->Ld);
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
-    gemm<NP, false>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, eo);
+    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, eo);
   }
   // decoder_norm + spec_out_dense (network.py:445-456).  The reference keeps this
   // projection in float32 "for stability": its output eps enters x0 = sqrt(1+e^-l)(z - s eps)
@@ -767,7 +794,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
   } else {
     EpiStoreF32 ef;
     ef.out = m->eps; ef.ldc = m->ND; ef.rsc = rowscale(nullptr, 0);
-    gemm<NP, false>(c, KC_FINAL_PROJ, m->y, D, m->w_out_p, D, M, m->ND, D, ef);
+    gemm<NP, TK_NARROW>(c, KC_FINAL_PROJ, m->y, D, m->w_out_p, D, M, m->ND, D, ef);
   }
 }
 
@@ -784,7 +811,7 @@ void in_proj(Ctx& c, int batch, int P) {
   ei.x = m->x; ei.ldx = m->D; ei.pos = m->dec_pos; ei.T = m->T; ei.pass_rows = BT; ei.passes = P;
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
-  gemm<NP, false>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei);
+  gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei);
 }
 
 // z (fp32) -> bf16 planes, after z was written from outside the sampler kernel

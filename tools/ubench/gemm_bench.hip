@@ -83,6 +83,14 @@ int main() {
       double e3 = run<2, 64, 32, 3, true>(s.M, s.N, s.K, 200, s.resid);
       double e4 = run<2, 32, 32, 4, true>(s.M, s.N, s.K, 200, s.resid);
       printf("   DMA     bf16x3: 32x64 NS3 %6.1f NS4 %6.1f | 64x32 NS3 %6.1f | 32x32 NS4 %6.1f\n", e1, e2, e3, e4);
+      if (s.N % 96 == 0) printf("   DMA     bf16x3: 64x96 NS2 %6.1f | 128x96 NS2 %6.1f | cold 64x96 NS2 %6.1f\n", run<2, 64, 96, 2, true>(s.M, s.N, s.K, 200, s.resid),
+             run<2, 128, 96, 2, true>(s.M, s.N, s.K, 200, s.resid), run_cold<2, 64, 96, 2>(s.M, s.N, s.K, 192, s.resid));
+      if (s.N % 96 == 0) printf("   COLD 64x96 NS3 %6.1f | 32x96 NS3 %6.1f NS4 %6.1f\n", run_cold<2, 64, 96, 3>(s.M, s.N, s.K, 192, s.resid),
+             run_cold<2, 32, 96, 3>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 32, 96, 4>(s.M, s.N, s.K, 192, s.resid));
+      if (s.N % 128 == 0) printf("   COLD 64x128 NS2 %6.1f NS3 %6.1f | 32x128 NS3 %6.1f NS4 %6.1f\n", run_cold<2, 64, 128, 2>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 64, 128, 3>(s.M, s.N, s.K, 192, s.resid),
+             run_cold<2, 32, 128, 3>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 32, 128, 4>(s.M, s.N, s.K, 192, s.resid));
+      printf("   COLD 64x64 NS3 %6.1f NS4 %6.1f | 32x64 NS4 %6.1f | 64x32 NS4 %6.1f | 32x32 NS6 %6.1f\n", run_cold<2, 64, 64, 3>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 64, 64, 4>(s.M, s.N, s.K, 192, s.resid),
+             run_cold<2, 32, 64, 4>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 64, 32, 4>(s.M, s.N, s.K, 192, s.resid), run_cold<2, 32, 32, 6>(s.M, s.N, s.K, 192, s.resid));
       printf("   COLD weights (48 copies): 64x64 NS2 %6.1f | 32x32 NS4 %6.1f\n", run_cold<2, 64, 64, 2>(s.M, s.N, s.K, 192, s.resid),
              run_cold<2, 32, 32, 4>(s.M, s.N, s.K, 192, s.resid));
     }
