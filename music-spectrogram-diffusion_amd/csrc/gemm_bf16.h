@@ -322,6 +322,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) MSD_D_ISSUE(s, s)
+  // Epilogue operands (row statistics, step-indexed bias / gain rows, the residual tile) are
+  // HBM-cold and used to be read by dependent global loads AFTER the K loop (+2..4 us per
+  // launch).  They are DMAed into an aux LDS region behind the ring now, queued behind the
+  // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
+  // over-wait by these few instructions at kt = 0) and the final vmcnt(0) covers them.
+  char* const aux = smem + NS * STAGE_BYTES;
+  epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
 
   int buf = 0;  // LDS ring slot of tile kt
   for (int kt = 0; kt < nk; ++kt) {
@@ -385,7 +393,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
       *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
   __syncthreads();
-  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid);
+  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux);
 }
 
 // ----------------------------------------------------------------------------
@@ -439,17 +447,58 @@ struct RowScale {
   const int* step_ptr = nullptr;
 };
 
-// rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier
+constexpr int kAuxMaxTiles = 32;  // ssq partials per row the aux region is sized for (D <= 1024)
+
+typedef const __attribute__((address_space(1))) void* aux_gptr_t;
+typedef __attribute__((address_space(3))) void* aux_lptr_t;
+
+// LDS-DMA of `bytes` contiguous, 16-byte aligned global bytes to dst (linear), one 1 KiB
+// instruction per wave round-robin.  Lanes past the end re-fetch the last chunk; their LDS
+// writes land in the padding (dst needs round_up(bytes, 1024) bytes).
+__device__ __forceinline__ void aux_dma_linear(const void* g, char* dst, int bytes, int wave, int lane) {
+  const int n_instr = (bytes + 1023) >> 10;
+  for (int i = wave; i < n_instr; i += 4) {
+    int off = i * 1024 + lane * 16;
+    off = off < bytes - 16 ? off : bytes - 16;
+    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)(dst + i * 1024), 16, 0, 0);
+  }
+}
+
+// one instruction: `bytes` (<= 1024) contiguous global bytes to dst
+__device__ __forceinline__ void aux_dma_row(const void* g, char* dst, int bytes, int lane) {
+  int off = lane * 16;
+  off = off < bytes - 16 ? off : bytes - 16;
+  __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)dst, 16, 0, 0);
+}
+
+// RowScale aux layout: [BM * tiles ssq partials | pad to BM * kAuxMaxTiles floats][bias row, 1 KiB]
 template <int BM>
-__device__ __forceinline__ const float* tile_rstd(const RowScale& r, float* rs, int m0, int tid) {
+constexpr int rowscale_aux_bytes() { return BM * kAuxMaxTiles * 4 + 1024; }
+
+template <int BM, int BN>
+__device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, int m0, int n0, int wave, int lane) {
+  if (!r.ssq) return;
+  aux_dma_linear(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
+  if (r.bias && wave == 3)
+    aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + BM * kAuxMaxTiles * 4, BN * 4, lane);
+}
+
+// rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier.
+// Returns the bias row of THIS tile (index 0 = column n0), or nullptr.  With `aux` the
+// operands were prefetched by rowscale_prefetch; without, they are read from global memory.
+template <int BM>
+__device__ __forceinline__ const float* tile_rstd(const RowScale& r, float* rs, int m0, int n0, int tid,
+                                                  const char* aux) {
   if (tid < BM) {
-    const float* q = r.ssq + (size_t)(m0 + tid) * r.tiles;
+    const float* q = aux ? reinterpret_cast<const float*>(aux) + tid * r.tiles : r.ssq + (size_t)(m0 + tid) * r.tiles;
     float acc = 0.f;
     for (int t = 0; t < r.tiles; ++t) acc += q[t];
     rs[tid] = 1.0f / sqrtf(acc * r.inv_d + 1e-6f);
   }
   __syncthreads();
-  return r.bias ? r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride : nullptr;
+  if (!r.bias) return nullptr;
+  if (aux) return reinterpret_cast<const float*>(aux + BM * kAuxMaxTiles * 4);
+  return r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0;
 }
 
 // C (row-major bf16 planes) = acc [* rstd[m] + bias[n]]
@@ -458,18 +507,23 @@ struct EpiStoreBf16 {
   bf16_t* out[2];
   int ldc;
   RowScale rsc;
+  template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
     const float* bias = nullptr;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
       tile_row8<LD>(s0, m, n, v);
       if (rsc.ssq) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
       }
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
     }
@@ -485,11 +539,16 @@ struct EpiQKV {
   bf16_t* vt[2];
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
   RowScale rsc;
+  template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
     const float* bias = nullptr;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
         const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
@@ -497,7 +556,7 @@ struct EpiQKV {
         tile_row8<LD>(s0, m, n, v);
         if (rsc.ssq) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
         }
         store_bf16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
       }
@@ -510,7 +569,7 @@ struct EpiQKV {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
         if (rsc.ssq) {
-          const float bn = bias ? bias[n0 + n] : 0.f;
+          const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[mm + e] + bn;
         }
@@ -541,8 +600,11 @@ struct EpiQKV {
 struct EpiResidual {
   float* x;
   int ldx;
+  template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
+  template <int BM, int BN>
+  __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -571,19 +633,49 @@ struct EpiResidualNorm {
   const float* g_hi; int g_hi_stride;
   int split_row;
   const int* step_ptr;
-  template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
-    static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile (tiles = D / BN)");
+  // aux layout (BN == 32 only): [x tile BM x 32 fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB]
+  template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 + 2048 : 0; }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    if (BN != 32) return;
+    // rows of 128 B: lane (r = lane>>3, c = lane&7) fetches 16 B of row 8i + r
+    for (int i = wave; i < BM / 8; i += 4)
+      __builtin_amdgcn_global_load_lds(
+          (aux_gptr_t)(x + (size_t)(m0 + 8 * i + (lane >> 3)) * ldx + n0 + (lane & 7) * 4),
+          (aux_lptr_t)(aux + i * 1024), 16, 0, 0);
     const int step = *step_ptr;
-    const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
-    const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
+    if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)step * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
+    if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
+  }
+  template <int BM, int BN, int LD>
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+    static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile (tiles = D / BN)");
+    const bool pre = aux && BN == 32;
+    const float* glo;
+    const float* ghi;
+    const float* xs = nullptr;
+    if (pre) {  // tile-relative LDS copies
+      xs = reinterpret_cast<const float*>(aux);
+      glo = g_lo ? reinterpret_cast<const float*>(aux + BM * 128) - n0 : nullptr;
+      ghi = g_hi ? reinterpret_cast<const float*>(aux + BM * 128 + 1024) - n0 : nullptr;
+    } else {
+      const int step = *step_ptr;
+      glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
+      ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
+    }
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;   // BN/8 consecutive lanes share a row
       float v[8];
       tile_row8<LD>(s0, m, n, v);
       const int row = m0 + m, col = n0 + n;
       float4* px = reinterpret_cast<float4*>(x + (size_t)row * ldx + col);
-      float4 a = px[0], b = px[1];
+      float4 a, b;
+      if (pre) {
+        a = *reinterpret_cast<const float4*>(xs + m * BN + n);
+        b = *reinterpret_cast<const float4*>(xs + m * BN + n + 4);
+      } else {
+        a = px[0]; b = px[1];
+      }
       v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
       v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
       px[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -621,8 +713,11 @@ struct EpiInProj {
   int tiles;
   const float* g; int g_stride;
   const int* step_ptr;
+  template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
+  template <int BM, int BN>
+  __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile");
     const float* gs = g + (size_t)(*step_ptr) * g_stride;
     for (int item = tid; item < BM * BN / 8; item += 256) {
@@ -661,18 +756,23 @@ struct EpiStoreF32 {
   float* out;
   int ldc;
   RowScale rsc;
+  template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
     const float* bias = nullptr;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
       tile_row8<LD>(s0, m, n, v);
       if (rsc.ssq) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n0 + n + e] : 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
       }
       float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
       po[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -690,13 +790,18 @@ struct EpiGeglu {
   bf16_t* out[2];
   int ldc;  // = F
   RowScale rsc;  // bias table is indexed by PACKED column
+  template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
     float* rs = s0 + BM * LD;
     const float* bias = nullptr;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, tid);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
       const int pc = (j / 16) * 32 + (j % 16);
@@ -706,8 +811,8 @@ struct EpiGeglu {
       if (rsc.ssq) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          a[e] = a[e] * rs[m] + (bias ? bias[n0 + pc + e] : 0.f);
-          b[e] = b[e] * rs[m] + (bias ? bias[n0 + pc + 16 + e] : 0.f);
+          a[e] = a[e] * rs[m] + (bias ? bias[pc + e] : 0.f);
+          b[e] = b[e] * rs[m] + (bias ? bias[pc + 16 + e] : 0.f);
         }
       }
 #pragma unroll
@@ -743,7 +848,7 @@ inline hipError_t launch_gemm_bf16(const GemmParams& p, const Epi& epi, hipStrea
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>
-constexpr int gemm_bf16_dma_smem() { return NS * NP * (BM + BN) * 128; }
+constexpr int gemm_bf16_dma_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN>(); }
 
 template <int NP, int BM, int BN, int NS, class Epi>
 inline hipError_t gemm_bf16_dma_prepare() {
