@@ -141,6 +141,9 @@ struct msd_model {
 
   hipGraphExec_t graph_exec = nullptr;
   int graph_batch = 0;
+  bool dual_chain = false;          // CFG passes as two concurrent graph branches (MSD_DUAL_CHAIN)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
   Profiler prof;
@@ -713,15 +716,31 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
 }
 
 template <int NP>
-void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
+void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
   msd_model* m = c.m;
   if (!m->fold_norm) { decoder_layers_unfolded<NP>(c, batch, P, cond0); return; }
+  // `row0`: first activation row of this chain (a multiple of T).  The conditional and the
+  // unconditional CFG pass never exchange data inside the decoder (self-attention is per
+  // segment), so enqueue_step can run them as two concurrent chains over disjoint row ranges.
+  auto shift = [&](const Planes& b, size_t elems) {
+    Planes r;
+    r.p[0] = b.p[0] + elems;
+    r.p[1] = b.p[1] ? b.p[1] + elems : nullptr;
+    return r;
+  };
   const int D = m->D, J = m->J, F = m->F, T = m->T;
   const int BT = batch * T, M = P * BT;
   const int slots = 2 * m->Ld, tiles = D / kNarrowTile;
+  const Planes y = shift(m->y, (size_t)row0 * D), qk = shift(m->qk, (size_t)row0 * 2 * J);
+  const Planes vts = shift(m->vt, (size_t)row0 * J), ao = shift(m->ao, (size_t)row0 * J);
+  const Planes gb = shift(m->g, (size_t)row0 * F);
+  float* const x = m->x + (size_t)row0 * D;
+  float* const ssq = m->ssq + (size_t)row0 * tiles;
+  float* const eps = m->eps + (size_t)row0 * m->ND;
+  const int* const nkeys_self = m->d_nkeys_self + row0 / T;
   auto rowscale = [&](const float* bias, int stride) {
     RowScale r;
-    r.ssq = m->ssq; r.tiles = tiles; r.inv_d = 1.0f / (float)D; r.bias = bias; r.bias_step_stride = stride;
+    r.ssq = ssq; r.tiles = tiles; r.inv_d = 1.0f / (float)D; r.bias = bias; r.bias_step_stride = stride;
     r.step_ptr = m->d_step;
     return r;
   };
@@ -732,52 +751,52 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     // through one norm kernel; later layers consume the folded-norm planes `y` written by the
     // previous layer's MLP output projection.
     EpiQKV<NP> eq;
-    eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
-    eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
+    eq.qk[0] = qk.p[0]; eq.qk[1] = qk.p[NP - 1];
+    eq.vt[0] = vts.p[0]; eq.vt[1] = vts.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
     eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
-    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
-    const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
-    attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
-                  (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
+    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
+    const bf16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
+    attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
+                  (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch);
     // out-projection + residual; produces y for the cross-attention norm (conditional rows:
     // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
     EpiResidualNorm<NP> er;
-    er.x = m->x; er.ldx = D; er.y[0] = m->y.p[0]; er.y[1] = m->y.p[NP - 1]; er.ssq = m->ssq; er.tiles = tiles;
+    er.x = x; er.ldx = D; er.y[0] = y.p[0]; er.y[1] = y.p[NP - 1]; er.ssq = ssq; er.tiles = tiles;
     er.step_ptr = m->d_step;
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, er);
+    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
       es.rsc = rowscale(nullptr, 0);
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, m->y, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
       vt.p[0] = m->vtc.p[0] + loff;
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
-                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
+                    (size_t)J * m->S_pad, ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
       EpiResidualNorm<NP> ec = er;
       ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
       ec.split_row = BT;
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, ec);
+      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, ao, J, w.wo_cross, J, BT, D, J, ec);
     }
     // (iii) MLP block (network.py:241-256)
     EpiGeglu<NP> eg;
-    eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
+    eg.out[0] = gb.p[0]; eg.out[1] = gb.p[NP - 1]; eg.ldc = F;
     eg.rsc = rowscale(m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F);
-    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, m->y, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg);
     EpiResidualNorm<NP> eo = er;
     const bool last = (l + 1 == m->Ld);
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
-    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, eo);
+    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo);
   }
   // decoder_norm + spec_out_dense (network.py:445-456).  The reference keeps this
   // projection in float32 "for stability": its output eps enters x0 = sqrt(1+e^-l)(z - s eps)
@@ -786,15 +805,15 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
   // exact-fp32 MFMA; the plain bf16 mode uses the folded bf16 GEMM like its other layers.
   if (NP == 2) {
     FinalProjParams fp;
-    fp.x = m->x; fp.wg = m->w_out_g; fp.ssq = m->ssq; fp.out = m->eps;
+    fp.x = x; fp.wg = m->w_out_g; fp.ssq = ssq; fp.out = eps;
     fp.M = M; fp.N = m->ND; fp.K = D; fp.tiles = tiles; fp.inv_d = 1.0f / (float)D;
     c.begin(KC_FINAL_PROJ);
     hipLaunchKernelGGL(final_proj_f32_kernel, dim3((M / 32) * (m->ND / 32)), dim3(256), 0, c.s, fp);
     c.end(KC_FINAL_PROJ);
   } else {
     EpiStoreF32 ef;
-    ef.out = m->eps; ef.ldc = m->ND; ef.rsc = rowscale(nullptr, 0);
-    gemm<NP, TK_NARROW>(c, KC_FINAL_PROJ, m->y, D, m->w_out_p, D, M, m->ND, D, ef);
+    ef.out = eps; ef.ldc = m->ND; ef.rsc = rowscale(nullptr, 0);
+    gemm<NP, TK_NARROW>(c, KC_FINAL_PROJ, y, D, m->w_out_p, D, M, m->ND, D, ef);
   }
 }
 
@@ -826,7 +845,21 @@ void enqueue_step(Ctx& c, int batch) {
   msd_model* m = c.m;
   const int P = m->passes;
   in_proj<NP>(c, batch, P);
-  decoder_layers<NP>(c, batch, P, true);
+  if (m->dual_chain && P == 2 && m->fold_norm && !m->prof.on) {
+    // two concurrent chains (graph branches): conditional rows [0, BT) with cross-attention on
+    // the caller's stream, unconditional rows [BT, 2BT) on the side stream; joined for the sampler
+    const int BT = batch * m->T;
+    hipError_t e = hipEventRecord(m->ev_fork, c.s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+    Ctx c2{m, m->side_stream};
+    decoder_layers<NP>(c2, batch, 1, false, BT);
+    if (e == hipSuccess) e = hipEventRecord(m->ev_join, m->side_stream);
+    decoder_layers<NP>(c, batch, 1, true, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c.s, m->ev_join, 0);
+    if (c.err == hipSuccess) c.err = c2.err != hipSuccess ? c2.err : e;
+  } else {
+    decoder_layers<NP>(c, batch, P, true);
+  }
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
@@ -893,6 +926,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->Bmax = cfg->max_batch;
   m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
   if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
+  if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   m->S_pad = round_up(m->L + m->C, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
   declare_weights(m);
@@ -957,6 +991,9 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   HIP_TRY(m, hipEventCreate(&m->prof.e0));
   HIP_TRY(m, hipEventCreate(&m->prof.e1));
   HIP_TRY(m, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  HIP_TRY(m, hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+  HIP_TRY(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  HIP_TRY(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   return MSD_OK;
 }
 
@@ -966,6 +1003,9 @@ void msd_destroy(msd_model* m) {
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->noise_own) (void)hipFree(m->noise_own);
   for (void* p : m->allocs) (void)hipFree(p);
   delete m;
