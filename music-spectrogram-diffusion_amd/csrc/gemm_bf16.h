@@ -319,68 +319,182 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / kGemmBK;
+  // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
+  for (int s = 0; s < NS; ++s)
     if (s < nk) MSD_D_ISSUE(s, s)
   // Epilogue operands (row statistics, step-indexed bias / gain rows, the residual tile) are
   // HBM-cold and used to be read by dependent global loads AFTER the K loop (+2..4 us per
   // launch).  They are DMAed into an aux LDS region behind the ring now, queued behind the
   // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
-  // over-wait by these few instructions at kt = 0) and the final vmcnt(0) covers them.
+  // over-wait by these few instructions) and the final vmcnt(0) covers them.
   char* const aux = smem + NS * STAGE_BYTES;
   epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
 
-  int buf = 0;  // LDS ring slot of tile kt
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt's DMAs are the oldest outstanding; up to NS-2 younger tiles stay in flight
-    if (kt + NS - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // every wave's part of tile kt landed; compute(kt-1) done everywhere
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + NS - 1 < nk) {
-      int nb = buf + NS - 1;
-      if (nb >= NS) nb -= NS;
-      MSD_D_ISSUE(kt + NS - 1, nb)   // into the slot compute(kt-1) just released
-    }
-    const char* base = smem + buf * STAGE_BYTES;
-    // all fragment reads of the K-tile are issued up front (both 32-wide halves); the
-    // MFMAs of the first half then run under the LDS latency of the second half
-    mfma_bf16x8 fa[2][NP][FM], fb[2][NP][FN];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int c = kk * 4 + (lane >> 4);
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-          fa[kk][pl][i] = *reinterpret_cast<const mfma_bf16x8*>(
-              base + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c));
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          fb[kk][pl][j] = *reinterpret_cast<const mfma_bf16x8*>(
-              base + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][0][j], fa[kk][0][i], acc[i][j], 0, 0, 0);
-          if (NP == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][NP - 1][j], fa[kk][0][i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][0][j], fa[kk][NP - 1][i], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    buf = (buf + 1 == NS) ? 0 : buf + 1;
+  // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF
+#define MSD_D_READ(FA, FB, BUF, KK)                                                          \
+  {                                                                                          \
+    const char* base_ = smem + (BUF) * STAGE_BYTES;                                          \
+    const int c_ = (KK) * 4 + (lane >> 4);                                                   \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                      \
+      _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+        FA[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(                                   \
+            base_ + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c_));        \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                         \
+        FB[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(                                   \
+            base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c_)); \
+    }                                                                                        \
   }
+#define MSD_D_MFMA(FA, FB)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < FM; ++i)                                             \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                         \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[0][j], FA[0][i], acc[i][j], 0, 0, 0); \
+      if (NP == 2) {                                                                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[NP - 1][j], FA[0][i], acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[0][j], FA[NP - 1][i], acc[i][j], 0, 0, 0); \
+      }                                                                                      \
+    }
+
+  // ---- main loop, software-pipelined by half K-tiles ----------------------------------
+  // The LDS fragment reads of one half always run under the MFMAs of the previous half, also
+  // across the tile boundary: the per-tile barrier sits in the MIDDLE of tile kt (after its
+  // last reads were issued), where it frees slot kt for the DMA of tile kt+NS and publishes
+  // tile kt+1.  Before, every wave read a whole tile and then multiplied: LDS and MFMA pipes
+  // alternated (64x96 tile: ~640 + ~580 clocks per K-tile) instead of overlapping.
+  mfma_bf16x8 fa0[NP][FM], fb0[NP][FN], fa1[NP][FM], fb1[NP][FN];
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 2   // ablation (tools/ubench): no LDS fragment reads
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa0[pl][i] = fa1[pl][i] = mfma_bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb0[pl][j] = fb1[pl][j] = mfma_bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+  }
+#undef MSD_D_READ
+#define MSD_D_READ(FA, FB, BUF, KK) {}
+#endif
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 1   // ablation: no MFMA (fragments kept live)
+#undef MSD_D_MFMA
+#define MSD_D_MFMA(FA, FB)                                                                   \
+  _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                        \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(FA[pl][i]));       \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(FB[pl][j]));       \
+  }
+#endif
+  // Fine-grained issue order inside one half step: the wave's DMA and ds_read instructions
+  // are spread between its MFMAs, one group per slot q: [DMA q | ds_read q | MFMAs].  Issued
+  // as a block they sit in front of the MFMAs in the in-order instruction stream while the
+  // CU's address unit (64 B/clk, shared by the four waves) drains them -- the ablation in
+  // tools/ubench/gemm_abl.hip showed DMA, LDS-read and MFMA time ADDING UP (0.28 + 0.19 +
+  // 0.27 us per 64x96 K-tile) instead of overlapping.  Each slot is pinned by a sched_barrier.
+  constexpr int RD = NP * (FM + FN);                    // ds_read_b128 per half step (== PW)
+  constexpr int MQ = (NP == 2 ? 3 : 1) * FM * FN;       // MFMAs per half step
+  constexpr int MPR = MQ / RD;                          // MFMAs per slot (remainder in the last)
+  static_assert(PW == RD, "one DMA and one fragment read per slot");
+  // DMA number Q of K-tile KT into slot BUF (same enumeration as MSD_D_ISSUE)
+#define MSD_D_ISSUE1(KT, BUF, Q)                                                             \
+  {                                                                                          \
+    const int     pl_ = (Q) / (A_LD + B_LD), r_ = (Q) % (A_LD + B_LD);                       \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                                \
+    const int k0_ = (KT) * kGemmBK;                                                          \
+    if (r_ < A_LD)                                                                           \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga[pl_] + r_ * a_step + k0_),                \
+          (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, 0);     \
+    else                                                                                     \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl_] + (r_ - A_LD) * b_step + k0_),       \
+          (lptr_t)(base_ + NP * A_BYTES + pl_ * B_BYTES + (wave * (BN / 4) + 8 * (r_ - A_LD)) * 128), 16, 0, 0); \
+  }
+  // fragment read number Q of half KK of the tile in slot BUF
+#define MSD_D_READ1(FA, FB, BUF, KK, Q)                                                      \
+  {                                                                                          \
+    const int     pl_ = (Q) / (FM + FN), r_ = (Q) % (FM + FN);                               \
+    const char* base_ = smem + (BUF) * STAGE_BYTES;                                          \
+    const int c_ = (KK) * 4 + (lane >> 4);                                                   \
+    if (r_ < FM)                                                                             \
+      FA[pl_][r_ < FM ? r_ : 0] = *reinterpret_cast<const mfma_bf16x8*>(                     \
+          base_ + pl_ * A_BYTES + lds_tile_off(wm * WM + r_ * 16 + (lane & 15), c_));        \
+    else                                                                                     \
+      FB[pl_][r_ < FM ? 0 : r_ - FM] = *reinterpret_cast<const mfma_bf16x8*>(                \
+          base_ + NP * A_BYTES + pl_ * B_BYTES + lds_tile_off(wn * WN + (r_ - FM) * 16 + (lane & 15), c_)); \
+  }
+  // MFMA number E: products outermost, so one accumulator recurs every FM*FN MFMAs
+#define MSD_D_MFMA1(FA, FB, E)                                                               \
+  {                                                                                          \
+    const int     pr_ = (E) / (FM * FN), t_ = (E) % (FM * FN), i_ = t_ / FN, j_ = t_ % FN;    \
+    const int     pb_ = (pr_ == 1) ? NP - 1 : 0, pa_ = (pr_ == 2) ? NP - 1 : 0;              \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[pb_][j_], FA[pa_][i_], acc[i_][j_], 0, 0, 0); \
+  }
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 1   // ablation: no MFMA
+#undef MSD_D_MFMA1
+#define MSD_D_MFMA1(FA, FB, E) { asm volatile("" ::"v"(FA[0][0]), "v"(FB[0][0])); }
+#endif
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 2   // ablation: no LDS fragment reads
+#undef MSD_D_READ1
+#define MSD_D_READ1(FA, FB, BUF, KK, Q) {}
+#endif
+  // one half step: DMA of tile KT (if DO_ISSUE) into BUF_I, reads of (BUF_R, KK) into FAn/FBn,
+  // MFMAs on FAc/FBc
+#define MSD_D_HALF(DO_ISSUE, KT, BUF_I, FAn, FBn, BUF_R, KK, DO_READ, FAc, FBc)              \
+  {                                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < RD; ++q_) {                                      \
+      if (DO_ISSUE) MSD_D_ISSUE1(KT, BUF_I, q_)                                              \
+      if (DO_READ) MSD_D_READ1(FAn, FBn, BUF_R, KK, q_)                                      \
+      _Pragma("unroll") for (int e_ = q_ * MPR; e_ < (q_ + 1 == RD ? MQ : (q_ + 1) * MPR); ++e_) \
+        MSD_D_MFMA1(FAc, FBc, e_)                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+  }
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 3   // ablation 3: no DMA inside the loop
+#define MSD_D_DOISSUE 0
+#else
+#define MSD_D_DOISSUE 1
+#endif
+  // one K-tile: [reads of half 1 | MFMAs of half 0] wait+barrier [DMA of tile kt+NS, reads of
+  // the next tile's half 0 | MFMAs of half 1]
+#define MSD_D_STEP(DO_ISSUE, VMWAIT)                                                         \
+  {                                                                                          \
+    MSD_D_HALF(0, 0, 0, fa1, fb1, buf, 1, 1, fa0, fb0)                                       \
+    int nb = buf + 1;                                                                        \
+    if (nb == NS) nb = 0;                                                                    \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMWAIT) : "memory"); /* tile kt+1 landed */     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): my reads of slot buf are complete */ \
+    __builtin_amdgcn_s_barrier();  /* slot buf free everywhere; tile kt+1 visible */         \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    MSD_D_HALF(DO_ISSUE, kt + NS, buf, fa0, fb0, nb, 0, 1, fa1, fb1)                         \
+    /* The next half's fragments landed long ago.  Saying so with a compiler-visible wait */ \
+    /* keeps hipcc from putting lgkmcnt(0) between the reads and the MFMAs at the loop   */ \
+    /* head (its back-edge merge is conservative), which serialised them.                */ \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                      \
+    buf = nb;                                                                                \
+  }
+
+  if (nk >= NS) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");  // tile 0 landed; NS-1 tiles in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  MSD_D_READ(fa0, fb0, 0, 0)
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  int buf = 0;  // LDS ring slot of tile kt
+  int kt = 0;
+  // steady state: unconditional DMA of tile kt+NS, tiles kt+2 .. kt+NS-1 stay in flight
+  for (; kt + NS < nk; ++kt) MSD_D_STEP(MSD_D_DOISSUE, (NS - 2) * PW)
+  // drain: the last NS tiles are all issued
+  for (; kt + 1 < nk; ++kt) MSD_D_STEP(0, 0)
+  // last tile
+  MSD_D_HALF(0, 0, 0, fa1, fb1, buf, 1, 1, fa0, fb0)
+  MSD_D_HALF(0, 0, 0, fa0, fb0, buf, 0, 0, fa1, fb1)
+#undef MSD_D_STEP
+#undef MSD_D_HALF
+#undef MSD_D_ISSUE1
+#undef MSD_D_READ1
+#undef MSD_D_MFMA1
+#undef MSD_D_DOISSUE
+#undef MSD_D_READ
+#undef MSD_D_MFMA
 #undef MSD_D_ISSUE
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
 
@@ -619,7 +733,7 @@ struct EpiResidual {
 };
 
 // Residual add that also PRODUCES the folded-norm inputs of the next projection:
-//   x += acc ;  ssq[m][n0/64] = sum over this tile's 64 columns of x^2 ;
+//   x += acc ;  ssq[m][col/32] = sum over each 32-column group of x^2 ;
 //   y = x (.) g  as bf16 planes, g = g_lo for rows < split_row, g_hi otherwise
 //   (g pointer = base + step * step_stride; a null base skips y for that row range).
 template <int NP>
@@ -649,7 +763,7 @@ struct EpiResidualNorm {
   }
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
-    static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile (tiles = D / BN)");
+    static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
     const bool pre = aux && BN == 32;
     const float* glo;
     const float* ghi;
@@ -683,10 +797,9 @@ struct EpiResidualNorm {
       float sq = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
-      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 1, 64);   // 4 consecutive lanes = one 32-column group of one row
       sq += __shfl_xor(sq, 2, 64);
-      if (BN == 64) sq += __shfl_xor(sq, 4, 64);
-      if ((item % (BN / 8)) == 0) ssq[(size_t)row * tiles + n0 / BN] = sq;
+      if ((item & 3) == 0) ssq[(size_t)row * tiles + col / 32] = sq;
       const float* g = row < split_row ? glo : ghi;
       if (g) {
         const float4 g0 = *reinterpret_cast<const float4*>(g + col);

@@ -299,7 +299,7 @@ GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, 
 // At 64 x 64 the N = D projections have 96 blocks and are bound by the per-CU ingest rate
 // (~31 B/clk with one block per CU), hence the small tiles there.
 constexpr int kNarrowTile = 32;  // BN of every GEMM that feeds the folded-norm ssq partials
-enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3 };
+enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3, TK_SQUARE = 4 };
 
 template <int NP, int BM, int BN, int NS, class Epi>
 void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
@@ -314,22 +314,42 @@ constexpr int wide_ns(int np) { return np == 2 ? 2 : 3; }
 
 // `align` = the largest column granularity the epilogue tolerates besides N itself (QKV: the
 // V^T region must start on a tile boundary).
+// Batched songs (M = passes * B * T >= 2048): every CU has several tiles anyway, so the tiles
+// grow to 128 x 96/128 (2-deep ring, 128 KiB) -- half the L2->LDS re-reads per MAC
+// (tools/ubench/gemm_bench_big.hip, M = 4096: QKV 85 -> 61 us, MLP-in 114 -> 95, MLP-out 68 -> 48).
+constexpr int kBigM = 2048;
+
 template <int NP, int TK, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi, int align = 0) {
+  const bool big = NP == 2 && M >= kBigM && M % 128 == 0;
   if constexpr (TK == TK_QKV) {
-    if (NP == 2 && N % 96 == 0 && align % 96 == 0)
-      return gemm_t<NP, 64, 96, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    if constexpr (NP == 2) {
+      if (big && N % 96 == 0 && align % 96 == 0)
+        return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+      if (N % 96 == 0 && align % 96 == 0)
+        return gemm_t<NP, 64, 96, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    }
     return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
   }
   else if constexpr (TK == TK_MLP_IN) {
-    if (NP == 2 && N % 128 == 0)
-      return gemm_t<NP, 64, 128, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    if constexpr (NP == 2) {
+      if (big && N % 128 == 0)
+        return gemm_t<NP, 128, 128, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+      if (N % 128 == 0)
+        return gemm_t<NP, 64, 128, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    }
     return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
   }
   else {
-    if (TK == TK_TALL && M % 64 == 0)
-      return gemm_t<NP, 64, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    if constexpr (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE)) {   // the N = D projections of a decoder layer
+      if (big && N % 96 == 0)
+        return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    }
+    if constexpr (TK == TK_TALL) {
+      if (M % 64 == 0)
+        return gemm_t<NP, 64, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    }
     return gemm_t<NP, kNarrowTile, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
   }
 }
@@ -339,7 +359,11 @@ hipError_t prepare_gemms() {
   hipError_t e = hipSuccess, r;
 #define PREP(BM, BN, NS, EPI) if ((r = gemm_bf16_dma_prepare<NP, BM, BN, NS, EPI>()) != hipSuccess) e = r;
   PREP(64, 64, wide_ns(NP), EpiQKV<NP>) PREP(64, 64, wide_ns(NP), EpiGeglu<NP>)
-  if (NP == 2) { PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>) }
+  if constexpr (NP == 2) {
+    PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>)
+    PREP(128, 96, 2, EpiQKV<NP>) PREP(128, 128, 2, EpiGeglu<NP>)
+    PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreBf16<NP>)
+  }
   PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreBf16<NP>)
   PREP(32, 32, 4, EpiStoreF32) PREP(32, 32, 4, EpiInProj<NP>)
   PREP(64, 32, 4, EpiResidual) PREP(64, 32, 4, EpiResidualNorm<NP>)
@@ -566,7 +590,7 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->Lenc_pad, m->evt, m->Lenc_pad, 0, m->eao, J,
                   m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
-    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
+    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
     norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
     EpiGeglu<NP> eg;
     eg.out[0] = m->eg.p[0]; eg.out[1] = m->eg.p[NP - 1]; eg.ldc = F;
@@ -690,12 +714,12 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
     const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
                   (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
-    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
+    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
     if (cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -703,7 +727,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
                     (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
     }
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
     EpiGeglu<NP> eg;
@@ -767,13 +791,13 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    gemm<NP, TK_NARROW>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
+    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
       es.rsc = rowscale(nullptr, 0);
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross, D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -784,7 +808,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       EpiResidualNorm<NP> ec = er;
       ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
       ec.split_row = BT;
-      gemm<NP, TK_NARROW>(c, KC_GEMM_CROSS_OUT, ao, J, w.wo_cross, J, BT, D, J, ec);
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, ao, J, w.wo_cross, J, BT, D, J, ec);
     }
     // (iii) MLP block (network.py:241-256)
     EpiGeglu<NP> eg;

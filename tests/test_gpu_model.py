@@ -232,3 +232,37 @@ def test_empty_inputs_give_unconditional_result(tiny_ctx):
   ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
   assert np.isfinite(got).all()
   helpers.assert_fp32_class(got, ref64, ref32, 'empty')
+
+
+def test_batched_songs_use_big_tiles_and_match_oracle():
+  """16 songs per handle: M = 2*16*64 = 2048 rows -> the 128-row GEMM tiles of the batched
+  path (msd_api.hip kBigM).  emb 192 / 3 heads / mlp 256 make every N a multiple of the
+  96/128-column tiles so all big instantiations run; checked per song against the oracle."""
+  import dataclasses
+  base = msd_amd.config.preset('tiny_context', num_steps=4)
+  spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, emb_dim=192, num_heads=3))
+  params = msd_amd.synthetic.init_params(spec, 5, norm_scale_jitter=0.1)
+  B = 16
+  model = msd_amd.InferenceModel(params, spec, batch_size=B)
+  batch = helpers.make_batch(spec, batch=B, ctx_mask='ragged')
+  init_z, noise = helpers.make_noise(spec, batch=B)
+  got, _ = model.predict(batch, init_z=init_z, noise=noise)
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  helpers.assert_fp32_class(got, ref64, ref32, what='batched B=16')
+  # and one decoder pass, elementwise (no chaotic amplification)
+  import torch
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  fm = fast.FastModel(backend.NumpyBackend('float64'), cfg, dc, params, True)
+  fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+  nm = model._get_native()
+  z = np.random.default_rng(1).standard_normal((B, 64, 128)).astype(np.float32)
+  zd = torch.as_tensor(z).cuda()
+  for step, cond in [(3, True), (1, False)]:
+    eps = torch.zeros_like(zd)
+    nm.decoder_pass(B, step, zd, cond, eps)
+    torch.cuda.synchronize()
+    want = fm.decoder_pass(z.astype(np.float64), step, cond)
+    err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 2e-4, (step, cond, err)
