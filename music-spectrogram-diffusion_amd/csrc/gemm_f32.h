@@ -137,25 +137,41 @@ struct FinalProjParams {
   float inv_d;
 };
 
-__global__ void __launch_bounds__(256) final_proj_f32_kernel(FinalProjParams p) {
-  __shared__ __attribute__((aligned(16))) float red[4][32][33];
+constexpr int kFinalProjWaves = 8;   // K is split over the waves of a block (latency-bound: M*N is tiny)
+
+// RT: 16-row MFMA tiles per block (block tile = 16*RT rows x 32 columns)
+template <int RT>
+__global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(FinalProjParams p) {
+  constexpr int BMR = 16 * RT;
+  __shared__ __attribute__((aligned(16))) float red[kFinalProjWaves][BMR][33];
+  __shared__ float rstd[BMR];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nbn = p.N / 32;
-  const int m0 = (blockIdx.x / nbn) * 32, n0 = (blockIdx.x % nbn) * 32;
+  const int m0 = (blockIdx.x / nbn) * BMR, n0 = (blockIdx.x % nbn) * 32;
   const int g = lane >> 4, r = lane & 15;
-  f32x4 acc[2][2];
+  // row statistics once per row (wave 0), loads issued before the K loop
+  float ss = 0.f;
+  if (threadIdx.x < BMR) {
+    const float* q = p.ssq + (size_t)(m0 + threadIdx.x) * p.tiles;
+    for (int t = 0; t < p.tiles; ++t) ss += q[t];
+  }
+  f32x4 acc[RT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one MFMA K-step is 4 wide: lane (g, r) holds A[row r][k0 + 4g .. +3] and B[k0 + 4g + c][col r];
+  // a wave's slice is 16 wide (4 lane groups x 4), slices go round-robin over the waves.  The loop
+  // is unrolled so that the (HBM-cold) operand loads of all slices of a wave are in flight together.
   const float* xa = p.x + (size_t)(m0 + r) * p.K + 4 * g;
   const float* wb = p.wg + (size_t)(4 * g) * p.N + n0 + r;
-  for (int k0 = wave * 16; k0 < p.K; k0 += 64) {
-    float4 a[2];
+#pragma unroll 6
+  for (int k0 = wave * 16; k0 < p.K; k0 += 16 * kFinalProjWaves) {
+    float4 a[RT];
     float b[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + k0);
+    for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + k0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -163,7 +179,7 @@ __global__ void __launch_bounds__(256) final_proj_f32_kernel(FinalProjParams p) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < RT; ++i) {
         const float av = c == 0 ? a[i].x : (c == 1 ? a[i].y : (c == 2 ? a[i].z : a[i].w));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -171,21 +187,21 @@ __global__ void __launch_bounds__(256) final_proj_f32_kernel(FinalProjParams p) 
       }
     }
   }
+  if (threadIdx.x < BMR) rstd[threadIdx.x] = 1.0f / sqrtf(ss * p.inv_d + 1e-6f);
   // C layout: col = lane & 15, row = (lane >> 4) * 4 + e
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][i * 16 + g * 4 + e][j * 16 + r] = acc[i][j][e];
   __syncthreads();
-  for (int item = threadIdx.x; item < 32 * 32; item += 256) {
+  for (int item = threadIdx.x; item < BMR * 32; item += 64 * kFinalProjWaves) {
     const int m = item >> 5, n = item & 31;
-    const float v = red[0][m][n] + red[1][m][n] + red[2][m][n] + red[3][m][n];
-    const float* q = p.ssq + (size_t)(m0 + m) * p.tiles;
-    float ss = 0.f;
-    for (int t = 0; t < p.tiles; ++t) ss += q[t];
-    p.out[(size_t)(m0 + m) * p.N + n0 + n] = v * (1.0f / sqrtf(ss * p.inv_d + 1e-6f));
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFinalProjWaves; ++w) v += red[w][m][n];
+    p.out[(size_t)(m0 + m) * p.N + n0 + n] = v * rstd[m];
   }
 }
 

@@ -832,7 +832,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     fp.x = x; fp.wg = m->w_out_g; fp.ssq = ssq; fp.out = eps;
     fp.M = M; fp.N = m->ND; fp.K = D; fp.tiles = tiles; fp.inv_d = 1.0f / (float)D;
     c.begin(KC_FINAL_PROJ);
-    hipLaunchKernelGGL(final_proj_f32_kernel, dim3((M / 32) * (m->ND / 32)), dim3(256), 0, c.s, fp);
+    hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3((M / 16) * (m->ND / 32)), dim3(64 * kFinalProjWaves), 0, c.s, fp);
     c.end(KC_FINAL_PROJ);
   } else {
     EpiStoreF32 ef;
