@@ -65,6 +65,24 @@ def class_flops(spec, s_valid: float, passes: int):
   }
 
 
+def pmc_traffic(kernel_class, args):
+  """Fabric-side bytes per launch of `kernel_class` from the committed PMC passes
+  (profiles/pmc_traffic.json, made by tools/prof_pmc.sh + tools/pmc_traffic.py on this same
+  command).  rocprofv3 cannot run inside the timed process, so the number is the committed
+  measurement; it only applies to the configuration it was taken on (else null)."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+  if not os.path.exists(path):
+    return None, 'profiles/pmc_traffic.json not present'
+  if args.preset != 'base_with_context' or args.batch != 1 or args.precision != 'bf16x3' or args.cfg_weight == 1.0:
+    return None, 'PMC passes were taken on base_with_context, B=1, bf16x3, CFG'
+  with open(path) as f:
+    t = json.load(f)
+  for cls, v in t['per_class'].items():
+    if kernel_class in cls.split('+'):
+      return v['bytes_per_launch'], 'bytes per launch, %s; %s' % (t['source'], t['correction'])
+  return None, 'class %s not in profiles/pmc_traffic.json' % kernel_class
+
+
 def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0):
   """Oracle ('port') on the host cores: encoders once + `sample_steps` DDPM steps."""
   import torch
@@ -110,6 +128,36 @@ def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0)
   }
 
 
+def batched_leg(spec, args):
+  """Throughput lever outside the headline: several independent songs per GPU through the same
+  kernels (M = 2 * songs * 256 rows; 128-row GEMM tiles from 4 songs up).  One warm-up segment,
+  one timed segment per song."""
+  import torch
+  import msd_amd
+  nb = args.batched_songs
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb, precision=args.precision)
+  c_len = model.targets_context_length
+  pred = torch.zeros((nb, c_len, 128), dtype=torch.float32, device=model.device) if c_len is not None else None
+  t_frames = spec.task_feature_lengths['targets']
+  dt = 0.0
+  for k in range(2):
+    batch = {'encoder_input_tokens': np.concatenate(
+        [msd_amd.synthetic.segment_tokens(spec, 1000 * (7 + b) + k) for b in range(nb)], 0)}
+    if c_len is not None:
+      batch['encoder_continuous_inputs'] = pred
+      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((nb, c_len), np.int32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, _ = model.predict(batch, seed=0, segment=k, return_torch=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if c_len is not None:
+      pred = out
+  return {'songs_per_gpu': nb, 'value': round(nb * t_frames / dt, 3), 'unit': 'mel-frames/sec',
+          'ms_per_segment_batch': round(dt * 1e3, 2),
+          'note': 'same kernels, %d independent songs batched per handle; not the headline workload (SURVEY 8: B=1)' % nb}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -123,6 +171,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample-steps', type=int, default=20)
   ap.add_argument('--profile-steps', type=int, default=3)
+  ap.add_argument('--batched-songs', type=int, default=8,
+                  help='extra leg: this many songs per GPU in one handle (0/1 = skip); N=1 runs only')
   args = ap.parse_args()
 
   import torch
@@ -207,12 +257,16 @@ def main():
       if launches:
         per_class[name] = {'ms_per_launch': ms / launches, 'launches_per_step': launches / args.profile_steps,
                            'ms_per_step': ms / args.profile_steps}
-    dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_step'])
+    # dominant kernel = the longest single launch of the step (the class whose template also has
+    # the most algorithmic FLOPs); per-step totals by class are listed in per_class_ms_per_step
+    dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_launch'])
     achieved = flops[dom] / (per_class[dom]['ms_per_launch'] * 1e-3) / 1e12
     step_flops = sum(flops[n] * per_class[n]['launches_per_step'] for n in per_class if n in flops)
+    traffic, traffic_note = pmc_traffic(dom, args)
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 5), 'traffic': None,
+        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 5), 'traffic': traffic,
+        'traffic_note': traffic_note,
         'kernel_ms_per_launch': round(per_class[dom]['ms_per_launch'], 5),
         'algorithmic_gflop_per_launch': round(flops[dom] / 1e9, 4),
         'whole_step': {
@@ -232,14 +286,18 @@ def main():
         'dtype': 'bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/norm/softmax/sampler)'
                  if args.precision == 'bf16x3' else 'bf16',
         'data': 'synthetic (seeded tokens, reference-initialiser weights, Philox noise)',
-        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, segment-sequential with '
-                               'context hand-off, %d segments of %d frames per song'
-                               % (args.preset, args.num_steps, args.cfg_weight, nb, args.steps, t_frames),
+        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, %s, %d segments of %d frames per song'
+                               % (args.preset, args.num_steps, args.cfg_weight, nb,
+                                  'segment-sequential with context hand-off' if c_len is not None
+                                  else 'independent segments (no context), one after the other',
+                                  args.steps, t_frames),
                    'precision': args.precision, 'parallelism': 'song-parallel x%d' % world},
         'encode_ms_per_segment': round(enc_s / args.steps * 1e3, 3),
         'sample_ms_per_segment': round(smp_s / args.steps * 1e3, 3),
         'roofline': roofline,
     }
+    if world == 1 and args.batched_songs > 1 and nb == 1:
+      result['batched'] = batched_leg(spec, args)
     if world == 1 and not args.no_cpu_baseline:
       batch = {'encoder_input_tokens': segs[-1][:1]}
       if c_len is not None:

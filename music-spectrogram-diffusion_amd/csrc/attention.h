@@ -133,11 +133,8 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
     }                                                                                             \
   }
 
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nst) MSD_A_ISSUE(s, s)
-
-  // ---- Q fragments (B operand of S^T = K.Q^T), straight from global -------------------
+  // ---- Q fragments (B operand of S^T = K.Q^T), straight from global; issued BEFORE the
+  // ring DMAs so that the counted vmcnt waits below see them as the oldest operations ----
   const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * 64 + qb * 32 + q_lane;
   frag8 qf[NP][4];
 #pragma unroll
@@ -147,6 +144,12 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
     for (int s = 0; s < 4; ++s) qf[pl][s] = ld_frag(qp + s * 16);
   }
 
+  __builtin_amdgcn_sched_barrier(0);
+  // all NS ring slots are free at the start: NS stages go in flight at once
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < nst) MSD_A_ISSUE(s, s)
+
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -154,20 +157,27 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
 
   int buf = 0;
   for (int st = 0; st < nst; ++st) {
-    if (st + NS - 2 < nst) {
+    // stage st must have landed.  Issued so far: stages 0 .. st+NS-2 (0 .. NS-1 at st = 0).
+    if (st == 0 && nst >= NS) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");
+    } else if (st > 0 && st + NS - 2 < nst && NS > 2) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();   // stage st visible everywhere; compute(st-1) done everywhere
     __builtin_amdgcn_sched_barrier(0);
-    if (st + NS - 1 < nst && MSD_ATT_ABL != 3) {
-      int nb = buf + NS - 1;
-      if (nb >= NS) nb -= NS;
-      MSD_A_ISSUE(st + NS - 1, nb)
-    }
+    // The DMA of stage st+NS-1 goes into the slot compute(st-1) just released.  It is issued
+    // AFTER this wave's S^T MFMAs (below): as the first thing after the barrier the eight
+    // waves' DMA instructions queue up at the CU's address unit and hold back the MFMAs
+    // behind them in the in-order instruction stream.
+    const bool do_issue = st > 0 && st + NS - 1 < nst && MSD_ATT_ABL != 3;
+    int nb = buf + NS - 1;
+    if (nb >= NS) nb -= NS;
     const int kb0 = (ks + st * p.ksplit) * kAttStageKeys + kg * 32;  // first key of this wave's block
-    if (kb0 < nkeys) {
+    if (kb0 >= nkeys) {
+      if (do_issue) MSD_A_ISSUE(st + NS - 1, nb)
+    } else {
       const char* kt = smem + buf * STAGE;
       const char* vt = kt + NP * kAttKBytes;
       // ---- S^T = K . Q^T ------------------------------------------------------------
@@ -188,6 +198,9 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NP - 1], qf[0][sx], s, 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_issue) MSD_A_ISSUE(st + NS - 1, nb)
+      __builtin_amdgcn_sched_barrier(0);
       // lane owns keys kb0 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
       float bmax = NEG;
       if (kb0 + 32 > nkeys) {  // only the last, ragged key block needs the bound

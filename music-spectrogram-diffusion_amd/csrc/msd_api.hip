@@ -415,6 +415,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
+  if (c.m->prof.on && ksplit > 1) c.m->prof.launches[kc] += 1;  // + attention_merge_kernel
 }
 
 template <class Epi>

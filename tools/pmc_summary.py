@@ -18,7 +18,8 @@ with open(path) as f:
     acc[k][row['Counter_Name']] += float(row['Counter_Value'])
     cnt[k][row['Counter_Name']] += 1
 names = sorted({c for k in acc for c in acc[k]})
-print('kernel,dispatches,' + ','.join(names))
+out = csv.writer(sys.stdout)   # kernel names contain commas (template arguments): quoted
+out.writerow(['kernel', 'dispatches'] + names)
 for k in sorted(acc):
   n = max(cnt[k].values())
-  print(k + ',' + str(n) + ',' + ','.join('%.1f' % (acc[k][c] / max(cnt[k][c], 1)) for c in names))
+  out.writerow([k, n] + ['%.1f' % (acc[k][c] / max(cnt[k][c], 1)) for c in names])
