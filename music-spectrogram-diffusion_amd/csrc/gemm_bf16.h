@@ -34,6 +34,7 @@ struct GemmParams {
   const bf16_t* B[2];
   int lda, ldb;
   int M, N, K;
+  int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -278,10 +279,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
   // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
   // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
+  // With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
+  // bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
+  // traffic when the activations are as large as the weights (N = D projections).
   const int nbm = p.M / BM, nbn = p.N / BN;
+  const int RX = p.xcd_rows, CX = 8 / RX;
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
-  const int bm = tt % nbm, bn = (tt / nbm) * 8 + xcd;
-  if (bn >= nbn) return;
+  const int nbm_x = (nbm + RX - 1) / RX;
+  const int bm = (tt % nbm_x) * RX + xcd / CX, bn = (tt / nbm_x) * CX + xcd % CX;
+  if (bn >= nbn || bm >= nbm) return;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
@@ -976,7 +982,8 @@ inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipS
   constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
   static const hipError_t attr = gemm_bf16_dma_prepare<NP, BM, BN, NS, Epi>();
   if (attr != hipSuccess) return attr;
-  const int grid = 8 * ((p.N / BN + 7) / 8) * (p.M / BM);
+  const int rx = p.xcd_rows, cx = 8 / rx;
+  const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
   hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
 }

@@ -305,7 +305,21 @@ template <int NP, int BM, int BN, int NS, class Epi>
 void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
             const Epi& epi) {
   c.begin(kc);
-  hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(gp<NP>(a, lda, b, ldb, M, N, K), epi, c.s);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  // XCD grid (gemm_bf16.h): rows x cols minimising the bytes each L2 has to fetch, A/rx + B*rx/8
+  {
+    const double abytes = (double)M * K, bbytes = (double)N * K;
+    int best = 1;
+    double cost = abytes + bbytes / 8;
+    for (int rx = 2; rx <= 4; rx *= 2) {
+      if ((M / BM) % rx) break;
+      const double cst = abytes / rx + bbytes * rx / 8;
+      if (cst < 0.9 * cost) { cost = cst; best = rx; }
+    }
+    if (const char* v = getenv("MSD_XCD_ROWS")) best = atoi(v) > 0 ? atoi(v) : best;
+    p.xcd_rows = ((M / BM) % best == 0) ? best : 1;
+  }
+  hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
