@@ -271,8 +271,12 @@ def test_batched_songs_use_big_tiles_and_match_oracle():
 def test_midi_in_synthesis(tiny_ctx, tmp_path):
   """MIDI file -> tokens (front end) -> chained segments on the device; equal to
   feeding the same tokens by hand, and to the oracle song on those tokens."""
+  import dataclasses
   from msd_amd.frontend import midi_io, note_sequences
-  spec, params, model = tiny_ctx
+  base = tiny_ctx[0]                        # tiny shapes, but the real 1536-entry MT3 vocabulary
+  spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, vocab_size=1536))
+  params = msd_amd.synthetic.init_params(spec, 4, norm_scale_jitter=0.1)
+  model = msd_amd.InferenceModel(params, spec)
   ns = note_sequences.NoteSequence()
   for k, (p, prog) in enumerate([(60, 0), (64, 0), (67, 40), (72, 40), (55, 0)]):
     ns.add_note(pitch=p, velocity=90, start_time=0.3 * k, end_time=0.3 * k + 1.1, program=prog)
