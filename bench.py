@@ -128,6 +128,33 @@ def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0)
   }
 
 
+def synthetic_midi_tokens(spec, seed, n_segments):
+  """Seeded synthetic song (4 pitched programs + drums, ~9 notes/s) -> MIDI bytes -> frontend tokens."""
+  import msd_amd
+  from msd_amd.frontend import midi_io, note_sequences, tokenizer
+  rng = np.random.default_rng(seed)
+  seconds = n_segments * spec.task_feature_lengths['targets'] * 320 / 16000.0
+  ns = note_sequences.NoteSequence()
+  for program in (0, 33, 48, 73):
+    t = 0.0
+    while t < seconds - 0.3:
+      dur = float(rng.choice([0.12, 0.25, 0.5, 1.0]))
+      for pitch in rng.choice(np.arange(36, 96), size=int(rng.integers(1, 4)), replace=False):
+        ns.add_note(pitch=int(pitch), velocity=int(rng.integers(40, 120)), start_time=round(t, 2),
+                    end_time=round(min(t + dur, seconds - 0.01), 2), program=program)
+      t += dur * float(rng.choice([0.5, 1.0, 1.0, 2.0]))
+  for k in range(int(seconds * 4)):
+    ns.add_note(pitch=int(rng.choice([36, 38, 42, 46])), velocity=100, start_time=k * 0.25, end_time=k * 0.25 + 0.05,
+                is_drum=True)
+  ns = note_sequences.trim_overlapping_notes(ns)
+  ns.total_time = seconds - 0.005
+  cfg = tokenizer.FrontendConfig.from_spec(spec)
+  toks = tokenizer.note_sequence_to_model_inputs(midi_io.parse_midi(midi_io.note_sequence_to_midi(ns, 500)), cfg,
+                                                 num_samples=int(seconds * 16000) - 1, on_too_long='truncate')
+  assert len(toks) == n_segments, (len(toks), n_segments)
+  return toks
+
+
 def batched_leg(spec, args):
   """Throughput lever outside the headline: several independent songs per GPU through the same
   kernels (M = 2 * songs * 256 rows; 128-row GEMM tiles from 4 songs up).  One warm-up segment,
@@ -170,6 +197,8 @@ def main():
   ap.add_argument('--batch', type=int, default=1, help='independent songs synthesized together per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample-steps', type=int, default=20)
+  ap.add_argument('--data', choices=['tokens', 'midi'], default='tokens',
+                  help="'tokens': BASELINE.md 4 synthetic token streams (headline); 'midi': synthetic MIDI songs through frontend/")
   ap.add_argument('--profile-steps', type=int, default=3)
   ap.add_argument('--batched-songs', type=int, default=8,
                   help='extra leg: this many songs per GPU in one handle (0/1 = skip); N=1 runs only')
@@ -198,8 +227,14 @@ def main():
   t_frames = spec.task_feature_lengths['targets']
   n_seg = args.warmup + args.steps
   # every rank plays its own synthetic song (different token streams per rank)
-  segs = [np.concatenate([msd_amd.synthetic.segment_tokens(spec, 1000 * (rank * nb + b) + k) for b in range(nb)], 0)
-          for k in range(n_seg)]
+  if args.data == 'midi':
+    # a seeded synthetic multi-instrument MIDI song per (rank, song), through the real front end
+    # (frontend/: MIDI bytes -> notes -> the reference's segment tokens)
+    songs = [synthetic_midi_tokens(spec, 1000 * (rank * nb + b), n_seg) for b in range(nb)]
+    segs = [np.concatenate([songs[b][k] for b in range(nb)], 0) for k in range(n_seg)]
+  else:
+    segs = [np.concatenate([msd_amd.synthetic.segment_tokens(spec, 1000 * (rank * nb + b) + k) for b in range(nb)], 0)
+            for k in range(n_seg)]
   c_len = model.targets_context_length
   pred = None
   if c_len is not None:
@@ -285,7 +320,8 @@ def main():
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/norm/softmax/sampler)'
                  if args.precision == 'bf16x3' else 'bf16',
-        'data': 'synthetic (seeded tokens, reference-initialiser weights, Philox noise)',
+        'data': ('synthetic (seeded tokens, reference-initialiser weights, Philox noise)' if args.data == 'tokens' else
+                 'synthetic (seeded MIDI songs through the front end, reference-initialiser weights, Philox noise)'),
         'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, %s, %d segments of %d frames per song'
                                % (args.preset, args.num_steps, args.cfg_weight, nb,
                                   'segment-sequential with context hand-off' if c_len is not None
