@@ -15,7 +15,8 @@ from . import native
 from . import inference
 from . import sharding
 from . import frontend
+from . import checkpoints
 from .inference import InferenceModel, parse_training_gin_file
 
 __all__ = ['config', 'synthetic', 'audio_codecs', 'gin_lite', 'native', 'inference',
-           'sharding', 'frontend', 'InferenceModel', 'parse_training_gin_file']
+           'sharding', 'frontend', 'checkpoints', 'InferenceModel', 'parse_training_gin_file']

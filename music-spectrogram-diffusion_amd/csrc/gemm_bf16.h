@@ -451,6 +451,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
       __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
   }
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 4   // ablation 4: no per-tile barrier (wrong results; timing only)
+#define MSD_D_BARRIER
+#else
+#define MSD_D_BARRIER __builtin_amdgcn_s_barrier();
+#endif
 #if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 3   // ablation 3: no DMA inside the loop
 #define MSD_D_DOISSUE 0
 #else
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     if (nb == NS) nb = 0;                                                                    \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMWAIT) : "memory"); /* tile kt+1 landed */     \
     __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): my reads of slot buf are complete */ \
-    __builtin_amdgcn_s_barrier();  /* slot buf free everywhere; tile kt+1 visible */         \
+    MSD_D_BARRIER  /* slot buf free everywhere; tile kt+1 visible */                         \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     MSD_D_HALF(DO_ISSUE, kt + NS, buf, fa0, fb0, nb, 0, 1, fa1, fb1)                         \
     /* The next half's fragments landed long ago.  Saying so with a compiler-visible wait */ \
@@ -499,6 +504,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
 #undef MSD_D_READ1
 #undef MSD_D_MFMA1
 #undef MSD_D_DOISSUE
+#undef MSD_D_BARRIER
 #undef MSD_D_READ
 #undef MSD_D_MFMA
 #undef MSD_D_ISSUE

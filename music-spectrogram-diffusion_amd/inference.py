@@ -144,11 +144,14 @@ def _load_checkpoint(path, spec: config_lib.ModelSpec) -> Tuple[Dict[str, np.nda
   elif path.endswith('.npz'):
     with np.load(path) as f:
       flat = {k: f[k] for k in f.files}
+  elif os.path.isdir(path):
+    # a T5X checkpoint directory, what the reference restores (inference.py:159-176)
+    from . import checkpoints
+    flat = checkpoints.load_t5x_checkpoint(path)
   else:
-    raise NotImplementedError(
-        'T5X (zarr/tensorstore) checkpoints are not readable here (SURVEY.md 8(f) N3); '
-        'give a .safetensors/.npz flat dict keyed by the Flax parameter names, or '
-        '"synthetic[:seed]"')
+    raise ValueError(
+        'checkpoint_path must be a T5X checkpoint directory, a .safetensors/.npz flat dict keyed by '
+        'the Flax parameter names, or "synthetic[:seed]": %r' % path)
   step = int(np.asarray(flat.pop('__step__', 0)))
   return {k: np.asarray(v, np.float32) for k, v in flat.items()}, step
 
