@@ -104,5 +104,5 @@ def test_checkpoint_loader_paths(tmp_path):
   np.savez(tmp_path / 'w.npz', __step__=np.int64(1234), **params)
   p2, step2 = inference._load_checkpoint(str(tmp_path / 'w.npz'), spec)
   assert step2 == 1234 and all(np.array_equal(p2[k], params[k]) for k in params)
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(ValueError):       # not a directory (T5X dirs are read: tests/test_checkpoints.py)
     inference._load_checkpoint('/some/t5x/checkpoint_500000', spec)
