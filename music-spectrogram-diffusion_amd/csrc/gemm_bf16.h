@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
 
-  // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF
+  // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF (prologue only; the
+  // loop uses the per-slot forms below)
 #define MSD_D_READ(FA, FB, BUF, KK)                                                          \
   {                                                                                          \
     const char* base_ = smem + (BUF) * STAGE_BYTES;                                          \
@@ -352,15 +353,6 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
             base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c_)); \
     }                                                                                        \
   }
-#define MSD_D_MFMA(FA, FB)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < FM; ++i)                                             \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                         \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[0][j], FA[0][i], acc[i][j], 0, 0, 0); \
-      if (NP == 2) {                                                                         \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[NP - 1][j], FA[0][i], acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[0][j], FA[NP - 1][i], acc[i][j], 0, 0, 0); \
-      }                                                                                      \
-    }
 
   // ---- main loop, software-pipelined by half K-tiles ----------------------------------
   // The LDS fragment reads of one half always run under the MFMAs of the previous half, also
@@ -379,14 +371,6 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   }
 #undef MSD_D_READ
 #define MSD_D_READ(FA, FB, BUF, KK) {}
-#endif
-#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 1   // ablation: no MFMA (fragments kept live)
-#undef MSD_D_MFMA
-#define MSD_D_MFMA(FA, FB)                                                                   \
-  _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                        \
-    _Pragma("unroll") for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(FA[pl][i]));       \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(FB[pl][j]));       \
-  }
 #endif
   // Fine-grained issue order inside one half step: the wave's DMA and ds_read instructions
   // are spread between its MFMAs, one group per slot q: [DMA q | ds_read q | MFMAs].  Issued
@@ -506,7 +490,6 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
 #undef MSD_D_DOISSUE
 #undef MSD_D_BARRIER
 #undef MSD_D_READ
-#undef MSD_D_MFMA
 #undef MSD_D_ISSUE
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
 

@@ -39,7 +39,7 @@ class FrontendConfig:
   include_ties: bool = True
   onsets_only: bool = False
   program_granularity: str = 'full'
-  additional_frames_for_encoding: int = 0   # MelGAN (audio_codecs.py: AudioCodec default)
+  additional_frames_for_encoding: int = 16  # MelGAN (audio_codecs.py:216-221): widens the FRAME slice only, not the tokens
 
   @property
   def frame_rate(self) -> float:
