@@ -324,7 +324,14 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.end(kc);
 }
 
-constexpr int wide_ns(int np) { return np == 2 ? 2 : 3; }
+constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
+
+// rounds of blocks over the 256 CUs x rows of operand per K-tile: the GEMMs sit on the per-CU ingest
+// path, so a launch costs about that; used to pick between tile shapes for a given (M, N)
+inline long tile_cost(int M, int N, int BM, int BN) {
+  const long blocks = (long)(M / BM) * (N / BN);
+  return ((blocks + 255) / 256) * (BM + BN);
+}
 
 // `align` = the largest column granularity the epilogue tolerates besides N itself (QKV: the
 // V^T region must start on a tile boundary).
@@ -341,7 +348,9 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     if constexpr (NP == 2) {
       if (big && N % 96 == 0 && align % 96 == 0)
         return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
-      if (N % 96 == 0 && align % 96 == 0)
+      // 64 x 96 = one block per CU at base (192 blocks); at the small model (N = 1152: 96 blocks)
+      // 64 x 64 fills the chip better
+      if (N % 96 == 0 && align % 96 == 0 && tile_cost(M, N, 64, 96) <= tile_cost(M, N, 64, 64))
         return gemm_t<NP, 64, 96, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
     }
     return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
@@ -350,7 +359,7 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     if constexpr (NP == 2) {
       if (big && N % 128 == 0)
         return gemm_t<NP, 128, 128, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
-      if (N % 128 == 0)
+      if (N % 128 == 0 && tile_cost(M, N, 64, 128) <= tile_cost(M, N, 64, 64))
         return gemm_t<NP, 64, 128, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
     }
     return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
@@ -361,7 +370,7 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
         return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
     }
     if constexpr (TK == TK_TALL) {
-      if (M % 64 == 0)
+      if (M % 64 == 0 && tile_cost(M, N, 64, kNarrowTile) <= tile_cost(M, N, kNarrowTile, kNarrowTile))
         return gemm_t<NP, 64, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
     }
     return gemm_t<NP, kNarrowTile, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
