@@ -62,25 +62,30 @@ __device__ __forceinline__ frag8 ld_frag(const bf16_t* p) {
 #define MSD_ATT_ABL 0  // ablation switch for tools/ubench/attn_bench.hip; 0 = the product kernel
 #endif
 
-constexpr int kAttQB = 2, kAttKG = 4, kAttWaves = kAttQB * kAttKG;
+constexpr int kAttKG = 4;   // key groups (waves along the 128 keys of a stage); QB query blocks of 32 rows -> QB * 4 waves
 constexpr int kAttStageKeys = kAttKG * 32;             // 128 keys per LDS stage
 constexpr int kAttKBytes = kAttStageKeys * 128;        // K tile  [128 keys][64 d] bf16
 constexpr int kAttVBytes = 64 * kAttStageKeys * 2;     // V^T tile [64 d][128 keys] bf16
 constexpr int kAttOLD = 68;                            // merge slab row stride (floats)
 constexpr int kAttWStride = 32 * kAttOLD + 64;         // per-wave merge slab (floats)
 
-template <int NP, int NS>
+template <int NP, int NS, int QB>
 constexpr int attention_smem() {
-  return (NS * NP * (kAttKBytes + kAttVBytes) > kAttWaves * kAttWStride * 4)
+  return (NS * NP * (kAttKBytes + kAttVBytes) > QB * kAttKG * kAttWStride * 4)
              ? NS * NP * (kAttKBytes + kAttVBytes)
-             : kAttWaves * kAttWStride * 4;
+             : QB * kAttKG * kAttWStride * 4;
 }
 
-template <int NP, int NS>
-__global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p) {
+// QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
+// QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
+// (decoder self-attention at B = 1: 12 heads x 4 x 2 passes = 96 blocks of 64 rows).
+template <int NP, int NS, int QB>
+__global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams p) {
+  constexpr int kRows = 32 * QB;                 // query rows per block
+  constexpr int JPW = 16 / (QB * kAttKG);        // K (and V^T) DMA instructions per wave, plane and stage
   constexpr float NEG = -1e30f;
   constexpr int STAGE = NP * (kAttKBytes + kAttVBytes);
-  constexpr int PW = 4 * NP;  // DMA instructions per wave per stage
+  constexpr int PW = 2 * JPW * NP;  // DMA instructions per wave per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,8 +123,8 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
     char* base_ = smem + (BUF) * STAGE;                                                           \
     const int kb_ = (ks + (ST) * p.ksplit) * kAttStageKeys;                                       \
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                           \
-      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                          \
-        const int j_ = 2 * wave + jj;                                                             \
+      _Pragma("unroll") for (int jj = 0; jj < JPW; ++jj) {                                        \
+        const int j_ = JPW * wave + jj;                                                           \
         int row_ = kb_ + 8 * j_ + kr;                                                             \
         row_ = row_ < last_row ? row_ : last_row;                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(kseg[pl] + (size_t)row_ * p.ldk),               \
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
 
   // ---- Q fragments (B operand of S^T = K.Q^T), straight from global; issued BEFORE the
   // ring DMAs so that the counted vmcnt waits below see them as the oldest operations ----
-  const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * 64 + qb * 32 + q_lane;
+  const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * kRows + qb * 32 + q_lane;
   frag8 qf[NP][4];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
     mine[32 * kAttOLD + 32 + q_lane] = l_run;
   }
   __syncthreads();
-  // 2 query blocks x 32 q x 8 groups of 8 d = 512 work items = one per thread
+  // QB query blocks x 32 q x 8 groups of 8 d = QB * 256 work items = one per thread
   {
     const int item = tid;
     const int mqb = item >> 8, q = (item >> 3) & 31, d0 = (item & 7) * 8;
@@ -316,7 +321,7 @@ __global__ void __launch_bounds__(kAttWaves * 64) attention_kernel(AttnParams p)
       acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
       acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
     }
-    const size_t row = (size_t)seg * p.q_rows_per_seg + blk * 64 + mqb * 32 + q;
+    const size_t row = (size_t)seg * p.q_rows_per_seg + blk * kRows + mqb * 32 + q;
     if (p.ksplit == 1) {
       const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
       float v[8];
@@ -365,23 +370,40 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   store_bf16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v);
 }
 
-template <int NP, int NS>
-inline hipError_t attention_prepare() {
-  constexpr int smem = attention_smem<NP, NS>();
+template <int NP, int NS, int QB>
+inline hipError_t attention_prepare_one() {
+  constexpr int smem = attention_smem<NP, NS, QB>();
   if (smem < 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 // NS: LDS ring depth (NP = 2: one stage is 64 KiB -> NS = 2; NP = 1: 32 KiB -> NS = 3)
 template <int NP>
+constexpr int attention_ns() { return (NP == 2) ? 2 : 3; }
+
+template <int NP, int NS = attention_ns<NP>()>
+inline hipError_t attention_prepare() {
+  const hipError_t a = attention_prepare_one<NP, NS, 1>(), b = attention_prepare_one<NP, NS, 2>();
+  return a != hipSuccess ? a : b;
+}
+
+template <int NP>
 inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hipStream_t stream) {
-  constexpr int NS = (NP == 2) ? 2 : 3;
-  constexpr int smem = attention_smem<NP, NS>();
+  constexpr int NS = attention_ns<NP>();
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((attention_kernel<NP, NS>), dim3(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs),
-                     dim3(kAttWaves * 64), smem, stream, p);
+  // 64-row blocks share K/V between two query blocks; when that leaves most of the 256 CUs without
+  // a block, 32-row blocks (twice as many) finish sooner
+  const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
+  constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
+  if (blocks64 < 128) {
+    hipLaunchKernelGGL((attention_kernel<NP, NS, 1>), dim3(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs),
+                       dim3(kAttKG * 64), smem1, stream, p);
+  } else {
+    hipLaunchKernelGGL((attention_kernel<NP, NS, 2>), dim3(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs),
+                       dim3(2 * kAttKG * 64), smem2, stream, p);
+  }
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;
     hipLaunchKernelGGL((attention_merge_kernel<NP>), dim3((items + 255) / 256), dim3(256), 0, stream, p, heads);
