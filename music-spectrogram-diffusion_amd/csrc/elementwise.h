@@ -93,7 +93,8 @@ struct SamplerParams {
   float* z;             // [n] in/out
   const float* const* noise_slot;  // device slot holding the [N][n] per-step draws pointer
   const float* coef;    // [N][kCoefCount]
-  int* step_ptr;        // scan index i (device); decremented by block 0 after use
+  int* step_ptr;        // scan index i (device); see step_from_slot1
+  int step_from_slot1 = 0;
   int n;                // batch*T*n_dims
   int passes;           // 2 with CFG
   float cond_wt;        // eval_condition_weight
@@ -103,7 +104,9 @@ struct SamplerParams {
 };
 
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
-  const int i = *p.step_ptr;
+  // step_from_slot1: the step's first kernel (in_proj) copied the index to slot 1 and nobody else
+  // reads slot 0 any more in this step, so this launch may decrement slot 0 itself
+  const int i = p.step_from_slot1 ? p.step_ptr[1] : p.step_ptr[0];
   const float* c = p.coef + (size_t)i * kCoefCount;
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx < p.n) {
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   // every block has read *step_ptr before any kernel of the next step can start
   // (kernel boundary); the decrement is ordered by the same boundary.
   __syncthreads();
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) p.step_ptr[1] = i - 1;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) p.step_ptr[p.step_from_slot1 ? 0 : 1] = i - 1;
 }
 
 // g[step][slot][k] = gamma[k] * (film_scale[step][slot][k] + 1): the column multiplier of a

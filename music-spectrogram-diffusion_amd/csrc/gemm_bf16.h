@@ -821,13 +821,18 @@ struct EpiInProj {
   int tiles;
   const float* g; int g_stride;
   const int* step_ptr;
+  int* step_copy = nullptr;   // = step_ptr when the sampler follows in the same step
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
   template <int BM, int BN>
   __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile");
-    const float* gs = g + (size_t)(*step_ptr) * g_stride;
+    const int step = *step_ptr;
+    // first kernel of the DDPM step: publish the index in slot 1 for the sampler (elementwise.h),
+    // which then owns slot 0 and decrements it without a separate launch
+    if (step_copy && m0 == 0 && n0 == 0 && tid == 0) step_copy[1] = step;
+    const float* gs = g + (size_t)step * g_stride;
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];

@@ -866,7 +866,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
 }
 
 template <int NP>
-void in_proj(Ctx& c, int batch, int P) {
+void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   msd_model* m = c.m;
   const int BT = batch * m->T;
   if (!m->fold_norm) {
@@ -878,6 +878,7 @@ void in_proj(Ctx& c, int batch, int P) {
   ei.x = m->x; ei.ldx = m->D; ei.pos = m->dec_pos; ei.T = m->T; ei.pass_rows = BT; ei.passes = P;
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
+  ei.step_copy = publish_step ? m->d_step : nullptr;
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei);
 }
 
@@ -892,7 +893,7 @@ template <int NP>
 void enqueue_step(Ctx& c, int batch) {
   msd_model* m = c.m;
   const int P = m->passes;
-  in_proj<NP>(c, batch, P);
+  in_proj<NP>(c, batch, P, /*publish_step=*/m->fold_norm);
   if (m->dual_chain && P == 2 && m->fold_norm && !m->prof.on) {
     // two concurrent chains (graph branches): conditional rows [0, BT) with cross-attention on
     // the caller's stream, unconditional rows [BT, 2BT) on the side stream; joined for the sampler
@@ -916,8 +917,9 @@ void enqueue_step(Ctx& c, int batch) {
   sp.z_hi = m->fold_norm ? m->zp.p[0] : nullptr;
   sp.z_lo = (m->fold_norm && m->NP == 2) ? m->zp.p[1] : nullptr;
   c.begin(KC_SAMPLER);
+  sp.step_from_slot1 = m->fold_norm ? 1 : 0;
   hipLaunchKernelGGL(sampler_step_kernel, dim3((sp.n / 4 + 255) / 256), dim3(256), 0, c.s, sp);
-  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
+  if (!m->fold_norm) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
   c.end(KC_SAMPLER);
 }
 
