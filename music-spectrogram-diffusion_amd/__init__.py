@@ -16,7 +16,8 @@ from . import inference
 from . import sharding
 from . import frontend
 from . import checkpoints
+from . import jax_random
 from .inference import InferenceModel, parse_training_gin_file
 
 __all__ = ['config', 'synthetic', 'audio_codecs', 'gin_lite', 'native', 'inference',
-           'sharding', 'frontend', 'checkpoints', 'InferenceModel', 'parse_training_gin_file']
+           'sharding', 'frontend', 'checkpoints', 'jax_random', 'InferenceModel', 'parse_training_gin_file']

@@ -258,13 +258,18 @@ class InferenceModel(object):
 
   # -- predict (inference.py:200-203) -----------------------------------------------
   def predict(self, batch: Mapping[str, Any], seed: int = 0, segment: int = 0,
-              init_z=None, noise=None, return_torch: bool = False):
+              init_z=None, noise=None, return_torch: bool = False, rng: str = 'philox'):
     """Predict one batch of 256-frame segments.
 
     batch: the model features of inference.py:113-136 (NumPy arrays or torch
       tensors); ``decoder_target_tokens`` is used for its shape only.
     seed / segment: key of the Philox generator (replaces PRNGKey(seed)).
     init_z [B,T,n] / noise [N,B,T,n]: explicit draws (the parity contract).
+    rng: 'philox' (default: the library's device generator, one stream per segment) or 'jax':
+      the draws jax.random would make for PRNGKey(seed) -- init_z = normal(key), step-i noise =
+      normal(fold_in(key, i)) -- restated on the host (jax_random.py) and cached per
+      (seed, batch).  Like the reference (beam/evaluation.py:209 calls predict(batch) with the default
+      seed for EVERY segment), `segment` does not enter the key in this mode.
     Returns (decodes float32 [B,T,n] in mel units, scores float32 [B] zeros).
     """
     torch = self._torch
@@ -290,6 +295,10 @@ class InferenceModel(object):
       nm.encode(b, tokens, ctx, mask, stream=s)
       t1 = time.perf_counter()
       out = torch.empty((b, t, n), dtype=torch.float32, device=dev)
+      if rng == 'jax' and init_z is None and noise is None:
+        init_z, noise = self._jax_noise(seed, b)
+      elif rng not in ('philox', 'jax'):
+        raise ValueError("rng must be 'philox' or 'jax': %r" % (rng,))
       z0 = None if init_z is None else _to_device(torch, init_z, dev, torch.float32)
       nz = None if noise is None else _to_device(torch, noise, dev, torch.float32)
       if z0 is not None and tuple(z0.shape) != (b, t, n):
@@ -305,10 +314,22 @@ class InferenceModel(object):
       return out, torch.zeros((b,), dtype=torch.float32, device=dev)
     return out.cpu().numpy(), scores
 
+  def _jax_noise(self, seed: int, b: int):
+    """Device-resident (init_z, noise) of jax_random.reference_noise, cached for the last (seed, b)."""
+    key = (int(seed), int(b))
+    if getattr(self, '_jax_noise_key', None) != key:
+      from . import jax_random
+      t, n = self.targets_length, self.audio_codec.n_dims
+      steps = self.spec.diffusion.sampler.schedule.num_steps
+      z, nz = jax_random.reference_noise(seed, (b, t, n), steps)
+      self._jax_noise_val = (self._torch.as_tensor(z).to(self.device), self._torch.as_tensor(nz).to(self.device))
+      self._jax_noise_key = key
+    return self._jax_noise_val
+
   # -- InferSong.process segment loop (beam/evaluation.py:161-223) ---------------------
   def predict_sequence(self, segments_tokens: Sequence[np.ndarray], seed: int = 0,
                        always_mask_context: bool = False, init_context: Optional[np.ndarray] = None,
-                       first_segment_index: int = 0, return_timing: bool = False):
+                       first_segment_index: int = 0, return_timing: bool = False, rng: str = 'philox'):
     """Synthesize a whole song: segments of int32 [inputs_length] (or [1, L]).
 
     Segment 0 runs with context zeros + mask 0 (beam/evaluation.py:195-198);
@@ -337,7 +358,7 @@ class InferenceModel(object):
         no_ctx = always_mask_context or (i == 0 and init_context is None)
         batch['encoder_continuous_mask'] = (np.zeros if no_ctx else np.ones)((1, c_len), np.int32)
       tick = time.perf_counter()
-      out, _ = self.predict(batch, seed=seed, segment=gi, return_torch=True)
+      out, _ = self.predict(batch, seed=seed, segment=gi, return_torch=True, rng=rng)
       if i != 0:
         seconds.append(time.perf_counter() - tick)
       if c_len is not None:

@@ -290,3 +290,20 @@ def test_midi_in_synthesis(tiny_ctx, tmp_path):
   b = model.predict_sequence(toks, seed=3)
   assert a.shape == (1, 2 * 64, 128) and np.array_equal(a, b)
   assert np.isfinite(a).all() and a.std() > 0.1
+
+
+def test_rng_jax_mode_uses_reference_draws(tiny_ctx):
+  """rng='jax': the draws of jax.random for PRNGKey(seed) (jax_random.py), independent of `segment`."""
+  from msd_amd import jax_random
+  spec, params, model = tiny_ctx
+  batch = helpers.make_batch(spec, batch=1)
+  got, _ = model.predict(batch, seed=5, segment=0, rng='jax')
+  z, nz = jax_random.reference_noise(5, (1, 64, 128), spec.diffusion.sampler.schedule.num_steps)
+  want, _ = model.predict(batch, init_z=z, noise=nz)
+  assert np.array_equal(got, want)
+  again, _ = model.predict(batch, seed=5, segment=3, rng='jax')       # the reference ignores the segment
+  assert np.array_equal(got, again)
+  other, _ = model.predict(batch, seed=6, rng='jax')
+  assert not np.array_equal(got, other)
+  with pytest.raises(ValueError):
+    model.predict(batch, rng='mt19937')
