@@ -3,7 +3,7 @@ float64 fixture and whether repeated runs are bit-identical (they must be: no at
 a difference means a race in a kernel).  GPU only."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import msd_amd
 from tests import helpers
 from tests.test_golden import GOLD

@@ -79,6 +79,6 @@ def assert_fp32_class(got, ref64, ref32, what=''):
         % (what, med_dev, med_f32, out_dev, out_f32, rms(got, ref64), rms(ref32, ref64)))
   assert med_dev <= 3 * med_f32 + 2e-6, 'bulk error is not fp32-class'
   # bf16x3 products carry ~2^-16 relative error against float32's 2^-24, so more marginal
-  # elements flip at the clip boundary of the first steps; tools/diag_fold_ab.py shows the
+  # elements flip at the clip boundary of the first steps; tests/diag/diag_fold_ab.py shows the
   # same device paths agreeing to 1e-5 relative once clipping is off.
   assert out_dev <= 4 * out_f32 + 2e-2, 'too many outliers'
