@@ -162,28 +162,38 @@ __global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(Fi
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // one MFMA K-step is 4 wide: lane (g, r) holds A[row r][k0 + 4g .. +3] and B[k0 + 4g + c][col r];
-  // a wave's slice is 16 wide (4 lane groups x 4), slices go round-robin over the waves.  The loop
-  // is unrolled so that the (HBM-cold) operand loads of all slices of a wave are in flight together.
+  // a wave's slice is 16 wide (4 lane groups x 4), slices go round-robin over the waves; the
+  // (HBM-cold) operand loads of U slices of a wave are issued together.
   const float* xa = p.x + (size_t)(m0 + r) * p.K + 4 * g;
   const float* wb = p.wg + (size_t)(4 * g) * p.N + n0 + r;
-#pragma unroll 6
-  for (int k0 = wave * 16; k0 < p.K; k0 += 16 * kFinalProjWaves) {
-    float4 a[RT];
-    float b[2][4];
+  constexpr int U = 6;   // K slices in flight per wave (768 / (16 * 8) = 6: one round at D = 768)
+  for (int kb = wave * 16; kb < p.K; kb += 16 * kFinalProjWaves * U) {
+    float4 a[U][RT];
+    float b[U][2][4];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + k0);
+    for (int u = 0; u < U; ++u) {          // all operand loads first (tail slices re-read slice kb, unused)
+      const int k0 = kb + u * 16 * kFinalProjWaves;
+      const int kk = k0 < p.K ? k0 : kb;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < RT; ++i) a[u][i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + kk);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b[j][c] = wb[(size_t)(k0 + c) * p.N + j * 16];
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 4; ++c) b[u][j][c] = wb[(size_t)(kk + c) * p.N + j * 16];
+    }
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const float av = c == 0 ? a[i].x : (c == 1 ? a[i].y : (c == 2 ? a[i].z : a[i].w));
+    for (int u = 0; u < U; ++u) {
+      if (kb + u * 16 * kFinalProjWaves < p.K) {   // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j][c], acc[i][j], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const float av = c == 0 ? a[u][i].x : (c == 1 ? a[u][i].y : (c == 2 ? a[u][i].z : a[u][i].w));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][j][c], acc[i][j], 0, 0, 0);
+          }
+        }
       }
     }
   }
