@@ -307,3 +307,38 @@ def test_rng_jax_mode_uses_reference_draws(tiny_ctx):
   assert not np.array_equal(got, other)
   with pytest.raises(ValueError):
     model.predict(batch, rng='mt19937')
+
+
+@pytest.mark.parametrize('valid', [1, 130, 1022])
+def test_key_split_cross_attention_edge_lengths(valid):
+  """inputs 1024 + context 64 -> S_pad >= 1024 -> the key-split cross-attention (4 blocks per query
+  group + merge).  Key counts at the extremes: blocks with NO stage of their own (1 valid token, with
+  and without context keys), a ragged last stage, a full key axis.  Single decoder passes against the
+  float64 oracle, elementwise (a short sampling chain would only add its own chaos, helpers.py)."""
+  import dataclasses
+  import torch
+  from oracle import backend, fast
+  base = msd_amd.config.preset('tiny_context', num_steps=3)
+  spec = dataclasses.replace(base, task_feature_lengths={'inputs': 1024, 'targets': 64, 'targets_context': 64})
+  params = msd_amd.synthetic.init_params(spec, 6, norm_scale_jitter=0.1)
+  model = msd_amd.InferenceModel(params, spec)
+  nm = model._get_native()
+  cfg, dc = helpers.oracle_configs(spec)
+  z = np.random.default_rng(0).standard_normal((1, 64, 128)).astype(np.float32)
+  zd = torch.as_tensor(z).cuda()
+  for mask in ('ragged', 'zeros', 'ones'):
+    batch = helpers.make_batch(spec, batch=1, ctx_mask=mask)
+    toks = batch['encoder_input_tokens']
+    toks[0, valid:] = 0
+    toks[0, :valid] = np.maximum(toks[0, :valid], 3)
+    toks[0, valid - 1] = 1
+    fm = fast.FastModel(backend.NumpyBackend('float64'), cfg, dc, params, True)
+    fm.encode(toks, batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+    nm.encode(1, toks, torch.as_tensor(batch['encoder_continuous_inputs']).cuda(), batch['encoder_continuous_mask'])
+    for step in (2, 0):
+      eps = torch.zeros_like(zd)
+      nm.decoder_pass(1, step, zd, True, eps)
+      torch.cuda.synchronize()
+      want = fm.decoder_pass(z.astype(np.float64), step, True)
+      err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
+      assert err < 2e-4, (valid, mask, step, err)
