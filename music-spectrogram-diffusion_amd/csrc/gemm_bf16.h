@@ -592,22 +592,44 @@ __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, 
     aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + BM * kAuxMaxTiles * 4, BN * 4, lane);
 }
 
-// rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier.
-// Returns the bias row of THIS tile (index 0 = column n0), or nullptr.  With `aux` the
-// operands were prefetched by rowscale_prefetch; without, they are read from global memory.
+typedef const __attribute__((address_space(3))) float* lds_cf32;   // explicit LDS pointer: ds_read, not flat_load
+
+// The bias row of a tile (index 0 = column n0): prefetched into LDS (aux) or read from global memory.
+struct BiasRow {
+  const float* g = nullptr;
+  lds_cf32 l = nullptr;
+  bool in_lds = false, present = false;
+  __device__ __forceinline__ float at(int i) const { return in_lds ? l[i] : g[i]; }
+};
+
+// rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier.  All 256
+// threads take part (256 / BM per row, then a shuffle tree): the serial 24-term sum by BM threads
+// over bank-conflicting LDS rows cost ~1 us per launch.  With `aux` the operands were prefetched by
+// rowscale_prefetch; without, they are read from global memory.
 template <int BM>
-__device__ __forceinline__ const float* tile_rstd(const RowScale& r, float* rs, int m0, int n0, int tid,
-                                                  const char* aux) {
-  if (tid < BM) {
-    const float* q = aux ? reinterpret_cast<const float*>(aux) + tid * r.tiles : r.ssq + (size_t)(m0 + tid) * r.tiles;
-    float acc = 0.f;
-    for (int t = 0; t < r.tiles; ++t) acc += q[t];
-    rs[tid] = 1.0f / sqrtf(acc * r.inv_d + 1e-6f);
+__device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m0, int n0, int tid,
+                                             const char* aux) {
+  constexpr int TPR = 256 / BM;
+  const int row = tid / TPR, part = tid % TPR;
+  float acc = 0.f;
+  if (aux) {
+    lds_cf32 q = (lds_cf32)(aux) + row * r.tiles;
+    for (int t = part; t < r.tiles; t += TPR) acc += q[t];
+  } else {
+    const float* q = r.ssq + (size_t)(m0 + row) * r.tiles;
+    for (int t = part; t < r.tiles; t += TPR) acc += q[t];
   }
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) acc += __shfl_xor(acc, o, 64);
+  if (part == 0) rs[row] = 1.0f / sqrtf(acc * r.inv_d + 1e-6f);
   __syncthreads();
-  if (!r.bias) return nullptr;
-  if (aux) return reinterpret_cast<const float*>(aux + BM * kAuxMaxTiles * 4);
-  return r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0;
+  BiasRow b;
+  if (r.bias) {
+    b.present = true;
+    if (aux) { b.in_lds = true; b.l = (lds_cf32)(aux + BM * kAuxMaxTiles * 4); }
+    else b.g = r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0;
+  }
+  return b;
 }
 
 // C (row-major bf16 planes) = acc [* rstd[m] + bias[n]]
@@ -624,7 +646,7 @@ struct EpiStoreBf16 {
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
-    const float* bias = nullptr;
+    BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
@@ -632,7 +654,7 @@ struct EpiStoreBf16 {
       tile_row8<LD>(s0, m, n, v);
       if (rsc.ssq) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
       }
       store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
     }
@@ -656,7 +678,7 @@ struct EpiQKV {
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
-    const float* bias = nullptr;
+    BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
@@ -665,7 +687,7 @@ struct EpiQKV {
         tile_row8<LD>(s0, m, n, v);
         if (rsc.ssq) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
         }
         store_bf16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
       }
@@ -678,7 +700,7 @@ struct EpiQKV {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
         if (rsc.ssq) {
-          const float bn = bias ? bias[n] : 0.f;
+          const float bn = bias.present ? bias.at(n) : 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[mm + e] + bn;
         }
@@ -760,31 +782,16 @@ struct EpiResidualNorm {
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
     const bool pre = aux && BN == 32;
-    const float* glo;
-    const float* ghi;
-    const float* xs = nullptr;
-    if (pre) {  // tile-relative LDS copies
-      xs = reinterpret_cast<const float*>(aux);
-      glo = g_lo ? reinterpret_cast<const float*>(aux + BM * 128) - n0 : nullptr;
-      ghi = g_hi ? reinterpret_cast<const float*>(aux + BM * 128 + 1024) - n0 : nullptr;
-    } else {
-      const int step = *step_ptr;
-      glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
-      ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
-    }
-    for (int item = tid; item < BM * BN / 8; item += 256) {
+    const int step = pre ? 0 : *step_ptr;
+    // one tile-element group (8 columns of one row); LX / LG fetch the residual and the gain
+    auto body = [&](int item, auto LX, auto LG) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;   // BN/8 consecutive lanes share a row
       float v[8];
       tile_row8<LD>(s0, m, n, v);
       const int row = m0 + m, col = n0 + n;
       float4* px = reinterpret_cast<float4*>(x + (size_t)row * ldx + col);
       float4 a, b;
-      if (pre) {
-        a = *reinterpret_cast<const float4*>(xs + m * BN + n);
-        b = *reinterpret_cast<const float4*>(xs + m * BN + n + 4);
-      } else {
-        a = px[0]; b = px[1];
-      }
+      LX(m, n, px, a, b);
       v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
       v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
       px[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -795,14 +802,38 @@ struct EpiResidualNorm {
       sq += __shfl_xor(sq, 1, 64);   // 4 consecutive lanes = one 32-column group of one row
       sq += __shfl_xor(sq, 2, 64);
       if ((item & 3) == 0) ssq[(size_t)row * tiles + col / 32] = sq;
-      const float* g = row < split_row ? glo : ghi;
-      if (g) {
-        const float4 g0 = *reinterpret_cast<const float4*>(g + col);
-        const float4 g1 = *reinterpret_cast<const float4*>(g + col + 4);
+      const bool lo_rows = row < split_row;
+      if (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr)) {
+        float4 g0, g1;
+        LG(lo_rows, n, col, g0, g1);
         v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
         v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
         store_bf16x8<NP>(y, (size_t)row * ldx + col, v);
       }
+    };
+    if (pre) {   // operands prefetched into the aux LDS region: explicit LDS pointers (ds_read)
+      typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;   // native vector: loadable from LDS
+      auto f4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+      lds_cf32x4 xs = (lds_cf32x4)(aux);
+      lds_cf32x4 gl = (lds_cf32x4)(aux + BM * 128), gh = (lds_cf32x4)(aux + BM * 128 + 1024);
+      for (int item = tid; item < BM * BN / 8; item += 256)
+        body(item,
+             [&](int m, int n, float4*, float4& a, float4& b) { a = f4(xs[(m * BN + n) / 4]); b = f4(xs[(m * BN + n) / 4 + 1]); },
+             [&](bool lo_rows, int n, int, float4& g0, float4& g1) {
+               g0 = f4(lo_rows ? gl[n / 4] : gh[n / 4]);
+               g1 = f4(lo_rows ? gl[n / 4 + 1] : gh[n / 4 + 1]);
+             });
+    } else {
+      const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
+      const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
+      for (int item = tid; item < BM * BN / 8; item += 256)
+        body(item,
+             [&](int, int, float4* px, float4& a, float4& b) { a = px[0]; b = px[1]; },
+             [&](bool lo_rows, int, int col, float4& g0, float4& g1) {
+               const float* g = lo_rows ? glo : ghi;
+               g0 = *reinterpret_cast<const float4*>(g + col);
+               g1 = *reinterpret_cast<const float4*>(g + col + 4);
+             });
     }
   }
 };
@@ -877,7 +908,7 @@ struct EpiStoreF32 {
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
     float* rs = s0 + BM * LD;
-    const float* bias = nullptr;
+    BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
@@ -885,7 +916,7 @@ struct EpiStoreF32 {
       tile_row8<LD>(s0, m, n, v);
       if (rsc.ssq) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias ? bias[n + e] : 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
       }
       float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
       po[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -913,7 +944,7 @@ struct EpiGeglu {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
     float* rs = s0 + BM * LD;
-    const float* bias = nullptr;
+    BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
@@ -924,8 +955,8 @@ struct EpiGeglu {
       if (rsc.ssq) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          a[e] = a[e] * rs[m] + (bias ? bias[pc + e] : 0.f);
-          b[e] = b[e] * rs[m] + (bias ? bias[pc + 16 + e] : 0.f);
+          a[e] = a[e] * rs[m] + (bias.present ? bias.at(pc + e) : 0.f);
+          b[e] = b[e] * rs[m] + (bias.present ? bias.at(pc + 16 + e) : 0.f);
         }
       }
 #pragma unroll
