@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {  # name, counters
   rm -rf /tmp/pmc_$1
   timeout 400 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d /tmp/pmc_$1 -- \
-      python $ROOT/bench.py --steps 1 --warmup 0 --num-steps 24 --no-cpu-baseline --profile-steps 1 > /tmp/pmc_$1.log 2>&1
+      python $ROOT/bench.py --steps 1 --warmup 0 --num-steps 24 --no-cpu-baseline --batched-songs 0 --profile-steps 1 > /tmp/pmc_$1.log 2>&1
   f=$(find /tmp/pmc_$1 -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python $ROOT/tools/pmc_summary.py $f > $ROOT/gpurun_out/pmc_${TAG}_$1.csv; else echo "no counters for $1"; tail -5 /tmp/pmc_$1.log; fi
 }
