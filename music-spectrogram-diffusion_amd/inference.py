@@ -275,7 +275,10 @@ class InferenceModel(object):
     torch = self._torch
     nm = self._get_native()
     dev = self.device
-    tokens = np.ascontiguousarray(_to_numpy(batch['encoder_input_tokens']), dtype=np.int32)
+    tokens = _to_numpy(batch['encoder_input_tokens'])
+    if tokens.dtype.kind not in 'iu':   # layers.Embed (layers.py:546-547; layers_test.py:392-401)
+      raise ValueError('Input type must be an integer or unsigned integer.')
+    tokens = np.ascontiguousarray(tokens, dtype=np.int32)
     b = tokens.shape[0]
     if tokens.ndim != 2 or tokens.shape[1] != self.inputs_length:
       raise ValueError('encoder_input_tokens must be [batch, %d]' % self.inputs_length)

@@ -136,7 +136,14 @@ def mlp_block(xp, params, prefix, inputs, activations):
 
 
 def embed_one_hot(xp, tokens, embedding):
-  """Embed with one_hot=True (layers.py:556-559): a row gather in exact arithmetic."""
+  """Embed with one_hot=True (layers.py:556-559): a row gather in exact arithmetic.  Non-integer
+  inputs are an error in the reference (layers.py:546-547; layers_test.py:392-401)."""
+  kind = getattr(getattr(tokens, 'dtype', None), 'kind', None)
+  if kind is None:   # torch tensors
+    import torch
+    kind = 'f' if isinstance(tokens, torch.Tensor) and tokens.dtype.is_floating_point else 'i'
+  if kind not in 'iu':
+    raise ValueError('Input type must be an integer or unsigned integer.')
   return xp.take(embedding, xp.asint(tokens))
 
 

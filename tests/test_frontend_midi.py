@@ -193,3 +193,13 @@ def test_trim_and_assign_instruments():
   many = note_sequences.note_arrays_to_note_sequence([0.0] * 12, list(range(60, 72)), programs=list(range(12)),
                                                      is_drums=[False] * 11 + [True])
   assert [n.instrument for n in many.notes] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 9]
+
+
+def test_synthesize_cli_dry_run(tmp_path, capsys):
+  from msd_amd import synthesize
+  ns = _random_song(9, seconds=12.0)
+  path = tmp_path / 'cli.mid'
+  path.write_bytes(midi_io.note_sequence_to_midi(ns, ticks_per_quarter=500))
+  assert synthesize.main([str(path), '--dry-run']) == 0
+  err = capsys.readouterr().err
+  assert '3 segments of 256 frames' in err and 'tokens per segment' in err

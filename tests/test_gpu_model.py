@@ -207,6 +207,10 @@ def test_error_paths(tiny_ctx):
   with pytest.raises(ValueError):
     model.predict(bad)
   bad = dict(batch)
+  bad['encoder_input_tokens'] = batch['encoder_input_tokens'].astype(np.float32)
+  with pytest.raises(ValueError, match='Input type must be an integer'):   # layers_test.py:392-401
+    model.predict(bad)
+  bad = dict(batch)
   bad['encoder_input_tokens'] = batch['encoder_input_tokens'] + 100000
   with pytest.raises(ValueError):
     model.predict(bad)

@@ -100,3 +100,14 @@ def test_mask_bias_is_exact_zero_weight():
   full = ops.dot_product_attention(xp, q, k2, v2, bias=bias)
   dropped = ops.dot_product_attention(xp, q, k, v)
   np.testing.assert_array_equal(full, dropped)
+
+
+def test_embedder_raises_for_non_integer_input():
+  """layers_test.py:392-401 ('Input type must be an integer or unsigned integer.')."""
+  from oracle import backend, ops
+  xp = backend.NumpyBackend('float64')
+  table = np.arange(50, dtype=np.float64).reshape(10, 5)
+  ids = np.arange(5, dtype=np.int64)[:, None]
+  np.testing.assert_array_equal(xp.to_numpy(ops.embed_one_hot(xp, ids, xp.asarray(table))), table[ids])
+  with pytest.raises(ValueError, match='Input type must be an integer or unsigned integer.'):
+    ops.embed_one_hot(xp, ids.astype(np.float32), xp.asarray(table))
