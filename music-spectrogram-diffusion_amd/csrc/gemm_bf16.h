@@ -501,8 +501,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     for (int j = 0; j < FN; ++j)
       *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
   __syncthreads();
-  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux);
+  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true);
 }
 
 // ----------------------------------------------------------------------------
@@ -607,8 +608,7 @@ struct BiasRow {
 // over bank-conflicting LDS rows cost ~1 us per launch.  With `aux` the operands were prefetched by
 // rowscale_prefetch; without, they are read from global memory.
 template <int BM>
-__device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m0, int n0, int tid,
-                                             const char* aux) {
+__device__ __forceinline__ void tile_rstd_compute(const RowScale& r, float* rs, int m0, int tid, const char* aux) {
   constexpr int TPR = 256 / BM;
   const int row = tid / TPR, part = tid % TPR;
   float acc = 0.f;
@@ -622,7 +622,17 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
 #pragma unroll
   for (int o = 1; o < TPR; o <<= 1) acc += __shfl_xor(acc, o, 64);
   if (part == 0) rs[row] = 1.0f / sqrtf(acc * r.inv_d + 1e-6f);
-  __syncthreads();
+}
+
+// `stats_done`: the caller already ran tile_rstd_compute ahead of its own barrier (the LDS-DMA kernel
+// does, next to its accumulator -> slab stores: one block barrier instead of two).
+template <int BM>
+__device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m0, int n0, int tid,
+                                             const char* aux, bool stats_done = false) {
+  if (!stats_done) {
+    tile_rstd_compute<BM>(r, rs, m0, tid, aux);
+    __syncthreads();
+  }
   BiasRow b;
   if (r.bias) {
     b.present = true;
@@ -643,11 +653,15 @@ struct EpiStoreBf16 {
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
   }
+  template <int BM, int LD>
+  __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
+    if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -675,11 +689,15 @@ struct EpiQKV {
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
   }
+  template <int BM, int LD>
+  __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
+    if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
         const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
@@ -734,8 +752,10 @@ struct EpiResidual {
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
   template <int BM, int BN>
   __device__ void prefetch(char*, int, int, int, int) const {}
+  template <int BM, int LD>
+  __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -766,6 +786,8 @@ struct EpiResidualNorm {
   const int* step_ptr;
   // aux layout (BN == 32 only): [x tile BM x 32 fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB]
   template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 + 2048 : 0; }
+  template <int BM, int LD>
+  __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     if (BN != 32) return;
@@ -779,7 +801,7 @@ struct EpiResidualNorm {
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
     const bool pre = aux && BN == 32;
     const int step = pre ? 0 : *step_ptr;
@@ -856,8 +878,10 @@ struct EpiInProj {
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
   template <int BM, int BN>
   __device__ void prefetch(char*, int, int, int, int) const {}
+  template <int BM, int LD>
+  __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile");
     const int step = *step_ptr;
     // first kernel of the DDPM step: publish the index in slot 1 for the sampler (elementwise.h),
@@ -905,11 +929,15 @@ struct EpiStoreF32 {
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
   }
+  template <int BM, int LD>
+  __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
+    if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -939,13 +967,17 @@ struct EpiGeglu {
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
   }
+  template <int BM, int LD>
+  __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
+    if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
+  }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
     float* rs = s0 + BM * LD;
     BiasRow bias;
-    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux);
+    if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
       const int pc = (j / 16) * 32 + (j % 16);
