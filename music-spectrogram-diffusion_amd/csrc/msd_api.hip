@@ -141,6 +141,8 @@ struct msd_model {
 
   hipGraphExec_t graph_exec = nullptr;
   int graph_batch = 0;
+  int graph_steps = 8;              // DDPM steps per graph launch (MSD_GRAPH_STEPS; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
+  hipGraphExec_t graph_exec1 = nullptr;   // single-step graph for N mod graph_steps
   bool dual_chain = false;          // CFG passes as two concurrent graph branches (MSD_DUAL_CHAIN)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -978,6 +980,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
   if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
+  if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
   m->S_pad = round_up(m->L + m->C, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
   declare_weights(m);
@@ -1051,6 +1054,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
 void msd_destroy(msd_model* m) {
   if (!m) return;
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph_exec1) (void)hipGraphExecDestroy(m->graph_exec1);
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -1219,23 +1223,39 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
 
-  if (!m->graph_exec || m->graph_batch != batch) {
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+  // One graph = `graph_steps` consecutive DDPM steps (the scan index lives in device memory, so
+  // the same graph serves every position); a second, single-step graph covers N mod graph_steps.
+  auto capture = [&](int steps, hipGraphExec_t* out) -> int {
     hipGraph_t graph = nullptr;
     HIP_TRY(m, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     Ctx c{m, s};
-    if (m->NP == 2) enqueue_step<2>(c, batch); else enqueue_step<1>(c, batch);
+    for (int k = 0; k < steps; ++k) {
+      if (m->NP == 2) enqueue_step<2>(c, batch); else enqueue_step<1>(c, batch);
+    }
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (ce != hipSuccess || c.err != hipSuccess) {
       if (graph) (void)hipGraphDestroy(graph);
       return fail(m, MSD_ERR_HIP, "graph capture failed: %s / %s", hipGetErrorString(ce), hipGetErrorString(c.err));
     }
-    hipError_t ie = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+    hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) { m->graph_exec = nullptr; return fail(m, MSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    if (ie != hipSuccess) { *out = nullptr; return fail(m, MSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    return MSD_OK;
+  };
+  if (!m->graph_exec || m->graph_batch != batch) {
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
+    int rc = capture(m->graph_steps, &m->graph_exec);
+    if (rc) return rc;
+    if (m->graph_steps > 1 && m->N % m->graph_steps) {
+      rc = capture(1, &m->graph_exec1);
+      if (rc) return rc;
+    }
     m->graph_batch = batch;
   }
-  for (int i = 0; i < m->N; ++i) HIP_TRY(m, hipGraphLaunch(m->graph_exec, s));
+  for (int i = 0; i < m->N / m->graph_steps; ++i) HIP_TRY(m, hipGraphLaunch(m->graph_exec, s));
+  for (int i = 0; i < m->N % m->graph_steps; ++i)
+    HIP_TRY(m, hipGraphLaunch(m->graph_steps > 1 ? m->graph_exec1 : m->graph_exec, s));
   hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, out_dev,
                      (int)n, m->cfg.feature_min, m->cfg.feature_max);
   HIP_TRY(m, hipGetLastError());
