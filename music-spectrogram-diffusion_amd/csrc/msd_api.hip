@@ -338,15 +338,18 @@ inline long tile_cost(int M, int N, int BM, int BN) {
 
 // `align` = the largest column granularity the epilogue tolerates besides N itself (QKV: the
 // V^T region must start on a tile boundary).
-// Batched songs (M = passes * B * T >= 2048): every CU has several tiles anyway, so the tiles
+// Batched songs (M = passes * B * T >= big_m_threshold() = 2048): every CU has several tiles anyway, so the tiles
 // grow to 128 x 96/128 (2-deep ring, 128 KiB) -- half the L2->LDS re-reads per MAC
 // (tools/ubench/gemm_bench_big.hip, M = 4096: QKV 85 -> 61 us, MLP-in 114 -> 95, MLP-out 68 -> 48).
-constexpr int kBigM = 2048;
+inline int big_m_threshold() {   // rows from which the 128-row tiles are used (MSD_BIG_M overrides)
+  static const int v = [] { const char* e = getenv("MSD_BIG_M"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+  return v;
+}
 
 template <int NP, int TK, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi, int align = 0) {
-  const bool big = NP == 2 && M >= kBigM && M % 128 == 0;
+  const bool big = NP == 2 && M >= big_m_threshold() && M % 128 == 0;
   if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
       if (big && N % 96 == 0 && align % 96 == 0)

@@ -240,7 +240,7 @@ def test_empty_inputs_give_unconditional_result(tiny_ctx):
 
 def test_batched_songs_use_big_tiles_and_match_oracle():
   """16 songs per handle: M = 2*16*64 = 2048 rows -> the 128-row GEMM tiles of the batched
-  path (msd_api.hip kBigM).  emb 192 / 3 heads / mlp 256 make every N a multiple of the
+  path (msd_api.hip big_m_threshold).  emb 192 / 3 heads / mlp 256 make every N a multiple of the
   96/128-column tiles so all big instantiations run; checked per song against the oracle."""
   import dataclasses
   base = msd_amd.config.preset('tiny_context', num_steps=4)
