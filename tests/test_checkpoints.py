@@ -112,3 +112,21 @@ def test_device_model_from_t5x_checkpoint(tmp_path):
   ya, _ = a.predict(batch, init_z=init_z, noise=noise)
   yb, _ = b.predict(batch, init_z=init_z, noise=noise)
   assert a.step == 5 and np.array_equal(ya, yb)
+
+
+def test_zarr_round_trip_property(tmp_path):
+  """Random ranks / shapes / chunkings / compressors (incl. chunks larger than the array)."""
+  from hypothesis import given, settings, strategies as st
+  counter = [0]
+
+  @settings(max_examples=40, deadline=None)
+  @given(st.lists(st.integers(1, 7), min_size=0, max_size=3), st.data())
+  def check(shape, data):
+    chunks = [data.draw(st.integers(1, s + 2)) for s in shape]
+    comp = data.draw(st.sampled_from(['gzip', 'zlib', None]))
+    arr = np.arange(int(np.prod(shape)) if shape else 1, dtype=np.float32).reshape(shape) * 0.5 - 3
+    counter[0] += 1
+    d = str(tmp_path / ('z%d' % counter[0]))
+    checkpoints.write_zarr_array(d, arr, compressor=comp, chunks=chunks if shape else None)
+    np.testing.assert_array_equal(checkpoints.read_zarr_array(d), arr)
+  check()
