@@ -309,18 +309,14 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
             const Epi& epi) {
   c.begin(kc);
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
-  // XCD grid (gemm_bf16.h): rows x cols minimising the bytes each L2 has to fetch, A/rx + B*rx/8
+  // XCD grid (gemm_bf16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
+  // (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
+  // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
+  // better than 1 x 8 everywhere.
   {
-    const double abytes = (double)M * K, bbytes = (double)N * K;
-    int best = 1;
-    double cost = abytes + bbytes / 8;
-    for (int rx = 2; rx <= 4; rx *= 2) {
-      if ((M / BM) % rx) break;
-      const double cst = abytes / rx + bbytes * rx / 8;
-      if (cst < 0.9 * cost) { cost = cst; best = rx; }
-    }
-    if (const char* v = getenv("MSD_XCD_ROWS")) best = atoi(v) > 0 ? atoi(v) : best;
-    p.xcd_rows = ((M / BM) % best == 0) ? best : 1;
+    int rx = 2;
+    if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
+    p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
   }
   hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
