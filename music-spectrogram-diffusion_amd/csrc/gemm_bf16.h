@@ -35,6 +35,7 @@ struct GemmParams {
   int lda, ldb;
   int M, N, K;
   int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
+  int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -285,8 +286,13 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   const int nbm = p.M / BM, nbn = p.N / BN;
   const int RX = p.xcd_rows, CX = 8 / RX;
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
-  const int nbm_x = (nbm + RX - 1) / RX;
-  const int bm = (tt % nbm_x) * RX + xcd / CX, bn = (tt / nbm_x) * CX + xcd % CX;
+  const int nbm_x = (nbm + RX - 1) / RX, nbn_x = (nbn + CX - 1) / CX;
+  int bm, bn;
+  if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
+    bm = (tt / nbn_x) * RX + xcd / CX; bn = (tt % nbn_x) * CX + xcd % CX;
+  } else {              // row tiles fastest (a weight slice stays hot)
+    bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
+  }
   if (bn >= nbn || bm >= nbm) return;
   const int m0 = bm * BM, n0 = bn * BN;
 

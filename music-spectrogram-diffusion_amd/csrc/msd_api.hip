@@ -317,6 +317,8 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
     int rx = 2;
     if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
     p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
+    static const int walk_n = [] { const char* e = getenv("MSD_XCD_WALK_N"); return e ? atoi(e) : 1; }();
+    p.xcd_walk_n = walk_n;
   }
   hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
