@@ -2,6 +2,8 @@
 // weight store + packing, step-indexed tables, encoder, the per-step kernel chain,
 // hipGraph capture/replay of one DDPM step, profiling.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <cctype>
+#include <cstdio>
 
 #include <cmath>
 #include <cstdarg>
@@ -314,10 +316,19 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
   // better than 1 x 8 everywhere.
   {
-    int rx = 2;
+    int rx = 2, walk_n = 1;
     if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
+    if (const char* v = getenv("MSD_XCD_WALK_N")) walk_n = atoi(v);
+    // per-class override for A/B runs: MSD_XCD_<class name, upper case>="rows,walk", e.g. MSD_XCD_GEMM_QKV=1,0
+    char name[64] = "MSD_XCD_";
+    size_t n = 8;
+    for (const char* q = kClassNames[kc]; *q && n + 1 < sizeof(name); ++q) name[n++] = (char)toupper(*q);
+    name[n] = 0;
+    if (const char* v = getenv(name)) {
+      int a = 0, b = 0;
+      if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0) { rx = a; walk_n = b; }
+    }
     p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
-    static const int walk_n = [] { const char* e = getenv("MSD_XCD_WALK_N"); return e ? atoi(e) : 1; }();
     p.xcd_walk_n = walk_n;
   }
   hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
