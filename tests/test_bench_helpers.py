@@ -1,0 +1,48 @@
+"""bench.py pieces that need no GPU: the FLOP model behind `roofline.achieved`, the committed PMC traffic
+lookup behind `roofline.traffic`, and the synthetic-MIDI workload generator (`--data midi`)."""
+import argparse
+import importlib.util
+import os
+
+import numpy as np
+
+import msd_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(bench)
+
+
+def test_class_flops_match_design_table():
+  spec = msd_amd.config.preset('base_with_context')
+  f = bench.class_flops(spec, 2304.0, 2)
+  assert f['gemm_mlp_in_geglu'] == 2.0 * 512 * 4096 * 768          # 3.22 GFLOP / launch
+  assert f['gemm_qkv'] == 2.0 * 512 * 2304 * 768
+  assert f['gemm_mlp_out'] == 2.0 * 512 * 768 * 2048
+  assert f['gemm_cross_q'] == 2.0 * 256 * 768 * 768                # conditional rows only (S4)
+  per_layer = sum(v for k, v in f.items() if k not in ('final_proj_f32', 'in_proj_f32'))
+  total = 12 * per_layer + f['final_proj_f32'] + f['in_proj_f32']
+  assert 100e9 < total < 130e9                                      # ~112-121 GFLOP per step
+
+
+def test_pmc_traffic_only_for_the_measured_configuration():
+  ok = argparse.Namespace(preset='base_with_context', batch=1, precision='bf16x3', cfg_weight=5.0)
+  val, note = bench.pmc_traffic('gemm_mlp_in_geglu', ok)
+  assert isinstance(val, int) and 10e6 < val < 100e6 and 'FETCH_SIZE' in note
+  for other in (dict(preset='small'), dict(batch=8), dict(precision='bf16'), dict(cfg_weight=1.0)):
+    ns = argparse.Namespace(**{**vars(ok), **other})
+    assert bench.pmc_traffic('gemm_mlp_in_geglu', ns)[0] is None
+  assert bench.pmc_traffic('no_such_class', ok)[0] is None
+
+
+def test_synthetic_midi_workload():
+  spec = msd_amd.config.preset('base_with_context')
+  toks = bench.synthetic_midi_tokens(spec, 7, 3)
+  assert len(toks) == 3
+  for t in toks:
+    assert t.shape == (1, 2048) and t.dtype == np.int32
+    n = int((t > 0).sum())
+    assert 100 < n < 2048 and t[0, n - 1] == 1 and t.max() < 1536
+  again = bench.synthetic_midi_tokens(spec, 7, 3)
+  assert all(np.array_equal(a, b) for a, b in zip(toks, again))
