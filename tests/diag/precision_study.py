@@ -1,0 +1,87 @@
+"""Which of the three split-bf16 products does attention actually need?  CPU study with the oracle's
+precision emulation (test infrastructure): the `small` 1000-step golden segment is re-run with
+attention variants that drop one hi/lo product, and the mel rms against the float64 fixture is
+printed next to the north-star bar (1e-3).  Guides kernel work; changes nothing in the product.
+  python -m tests.diag.precision_study [variant ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import msd_amd
+from oracle import backend, fast, philox
+from tests import helpers
+from tests.test_golden import GOLD
+
+VARIANTS = {
+    # name: (QK products, PV products); each product = (left part, right part), parts 0 = hi, 1 = lo
+    'x3':       ([(0, 0), (0, 1), (1, 0)], [(0, 0), (0, 1), (1, 0)]),   # the device's bf16x3
+    'pv_no_plo': ([(0, 0), (0, 1), (1, 0)], [(0, 0), (0, 1)]),          # P single plane
+    'pv_no_vlo': ([(0, 0), (0, 1), (1, 0)], [(0, 0), (1, 0)]),          # V single plane
+    'pv_1':     ([(0, 0), (0, 1), (1, 0)], [(0, 0)]),
+    'qk_no_qlo': ([(0, 0), (0, 1)], [(0, 0), (0, 1), (1, 0)]),          # Q single plane
+    'qk_no_klo': ([(0, 0), (1, 0)], [(0, 0), (0, 1), (1, 0)]),          # K single plane
+    'qk_1':     ([(0, 0)], [(0, 0), (0, 1), (1, 0)]),
+}
+
+
+# GEMM variants: products of (activation part, weight part)
+MM_VARIANTS = {
+    'mm_no_alo': [(0, 0), (0, 1)],     # activations single plane (weights hi + lo)
+    'mm_no_wlo': [(0, 0), (1, 0)],     # weights single plane (activations hi + lo)
+}
+
+
+class StudyModel(fast.FastModel):
+  variant = 'x3'
+
+  def _mm_parts(self, a_parts, w_parts):
+    if self.variant not in MM_VARIANTS:
+      return super()._mm_parts(a_parts, w_parts)
+    y = 0
+    for a, b in MM_VARIANTS[self.variant]:
+      y = y + self.xp.matmul(a_parts[a], w_parts[b])
+    return y
+
+  def _attend(self, q, k, v):
+    xp = self.xp
+    qk, pv = VARIANTS.get(self.variant, VARIANTS['x3'])
+    def split(a):
+      hi = xp.round_bf16(a)
+      return (hi, xp.round_bf16(a - hi))
+    qs, ks, vs = split(q), split(k), split(v)
+    s = 0
+    for a, b in qk:
+      s = s + xp.einsum('qhd,khd->hqk', qs[a], ks[b])
+    m = xp.max(s, axis=-1, keepdims=True)
+    pr = xp.exp(s - m)
+    l = xp.sum(pr, axis=-1, keepdims=True)
+    ps = split(pr)
+    o = 0
+    for a, b in pv:
+      o = o + xp.einsum('hqk,khd->hqd', ps[a], vs[b])
+    o = xp.einsum('hqd->qhd', o / l)
+    return xp.reshape(o, (q.shape[0], q.shape[1] * q.shape[2]))
+
+
+def main(names):
+  g = np.load(os.path.join(GOLD, 'small_n1000.npz'))
+  spec = msd_amd.config.preset('small', num_steps=1000)
+  params = msd_amd.synthetic.init_params(spec, 0)
+  cfg, dc = helpers.oracle_configs(spec)
+  t, n = spec.task_feature_lengths['targets'], 128
+  batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, 0)}
+  init_z, noise = philox.segment_noise((1, t, n), 1000, seed=int(g['noise_seed']), segment=0)
+  for name in names:
+    xp = backend.TorchBackend('float32', threads=backend.effective_cpus())
+    m = StudyModel(xp, cfg, dc, params, spec.has_context, precision='bf16x3')
+    m.variant = name
+    t0 = time.perf_counter()
+    out = xp.to_numpy(m.predict(batch, init_z, noise)[0])
+    print('%-10s rms vs float64 golden %.3e   (%.0f s)' % (name, helpers.rms(out[:, :t], g['mel'][:, :t]), time.perf_counter() - t0), flush=True)
+
+
+if __name__ == '__main__':
+  main(sys.argv[1:] or list(VARIANTS) + list(MM_VARIANTS))
