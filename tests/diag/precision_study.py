@@ -24,6 +24,7 @@ VARIANTS = {
     'qk_no_qlo': ([(0, 0), (0, 1)], [(0, 0), (0, 1), (1, 0)]),          # Q single plane
     'qk_no_klo': ([(0, 0), (1, 0)], [(0, 0), (0, 1), (1, 0)]),          # K single plane
     'qk_1':     ([(0, 0)], [(0, 0), (0, 1), (1, 0)]),
+    'q_p_single': ([(0, 0), (0, 1)], [(0, 0), (0, 1)]),                  # Q and P single plane (4 of 6 products)
 }
 
 
@@ -66,7 +67,31 @@ class StudyModel(fast.FastModel):
     return xp.reshape(o, (q.shape[0], q.shape[1] * q.shape[2]))
 
 
+def base_song(names):
+  """The two chained base_with_context golden segments (tests/golden/make_golden.py: song)."""
+  g = np.load(os.path.join(GOLD, 'base_with_context_n1000.npz'))
+  spec = msd_amd.config.preset('base_with_context', num_steps=1000)
+  params = msd_amd.synthetic.init_params(spec, 0)
+  cfg, dc = helpers.oracle_configs(spec)
+  t, n, c = 256, 128, 256
+  for name in names:
+    xp = backend.TorchBackend('float32', threads=backend.effective_cpus())
+    m = StudyModel(xp, cfg, dc, params, True, precision='bf16x3')
+    m.variant = name
+    pred = np.zeros((1, c, n), np.float32)
+    for k in range(int(g['n_segments'])):
+      t0 = time.perf_counter()
+      batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, k), 'encoder_continuous_inputs': pred,
+               'encoder_continuous_mask': (np.zeros if k == 0 else np.ones)((1, c), np.int32)}
+      init_z, noise = philox.segment_noise((1, t, n), 1000, seed=int(g['noise_seed']), segment=k)
+      pred = xp.to_numpy(m.predict(batch, init_z, noise)[0]).astype(np.float32)
+      print('base %-10s segment %d rms vs float64 golden %.3e   (%.0f s)'
+            % (name, k, helpers.rms(pred, g['mel'][:, k * t:(k + 1) * t]), time.perf_counter() - t0), flush=True)
+
+
 def main(names):
+  if names and names[0] == 'base':
+    return base_song(names[1:] or ['x3'])
   g = np.load(os.path.join(GOLD, 'small_n1000.npz'))
   spec = msd_amd.config.preset('small', num_steps=1000)
   params = msd_amd.synthetic.init_params(spec, 0)
