@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 1
+#define MSD_AMD_ABI_VERSION 2
 
 typedef struct msd_model msd_model; /* opaque */
 
@@ -65,10 +65,27 @@ typedef enum msd_sampler_kind {
   MSD_SAMPLER_DDIM = 1  /* diffusion_utils.py:369-379 */
 } msd_sampler_kind;
 
+typedef enum msd_schedule_kind {
+  MSD_SCHEDULE_COSINE = 0, /* diffusion_utils.py:181-187 */
+  MSD_SCHEDULE_LINEAR = 1  /* diffusion_utils.py:189-199: betas linspace(start, stop, num_steps) */
+} msd_schedule_kind;
+
+typedef enum msd_model_output {
+  MSD_OUTPUT_EPS = 0, /* diffusion_utils.py:296-300 */
+  MSD_OUTPUT_X0 = 1,  /* :301-305 */
+  MSD_OUTPUT_V = 2    /* :312-317 (x0_and_eps needs a 2n-channel network output, which the
+                         reference's own Decoder (network.py:451-456) cannot produce: rejected) */
+} msd_model_output;
+
+typedef enum msd_logvar_kind {
+  MSD_LOGVAR_LARGE = 0, /* diffusion_utils.py:146-149 */
+  MSD_LOGVAR_SMALL = 1, /* :142-145 */
+  MSD_LOGVAR_MEDIUM = 2 /* :150-157, "medium:<frac>" -> logvar_frac */
+} msd_logvar_kind;
+
 /* Hyper-parameters: network.T5Config (network.py:54-72), DiffusionConfig & co
  * (diffusion_utils.py:25-59), %TASK_FEATURE_LENGTHS (inference.py:97-101) and the
  * codec range (audio_codecs.py:207-213).  Fixed by construction on this path:
- * cosine schedules, model_output="eps", logvar_type="large",
  * decoder_cross_attend_style="concat_encodings", mlp_activations=("gelu","linear"),
  * head_dim=64; anything else is rejected by the Python layer / msd_create. */
 typedef struct msd_config {
@@ -95,6 +112,18 @@ typedef struct msd_config {
   float cfg_weight;               /* eval_condition_weight; 1.0 = single pass */
   float feature_min;              /* codec min_value */
   float feature_max;              /* codec max_value */
+  /* ABI 2: the sampler / schedule branches of diffusion_utils.py (all step-indexed table work) */
+  int32_t model_output;           /* msd_model_output: DiffusionConfig.model_output */
+  int32_t logvar_type;            /* msd_logvar_kind: SamplerConfig.logvar_type */
+  float logvar_frac;              /* the <frac> of "medium:<frac>", in [0, 1] */
+  int32_t sampler_schedule;       /* msd_schedule_kind of SamplerConfig.schedule (num_steps above) */
+  float sampler_schedule_start;   /* linear only */
+  float sampler_schedule_stop;
+  int32_t train_schedule;         /* msd_schedule_kind of DiffusionConfig.train_schedule: the log-SNR
+                                     at which the model output is converted (diffusion_utils.py:294) */
+  float train_schedule_start;     /* linear only */
+  float train_schedule_stop;
+  int32_t train_schedule_num_steps;
 } msd_config;
 
 const char* msd_version(void);
@@ -153,7 +182,8 @@ int msd_fill_normal(uint64_t seed, uint64_t stream_id, uint32_t subseq,
                     float* out_dev, int64_t n, void* stream);
 
 /* Step-indexed tables, for parity tests: copies [num_steps, 8] floats to host:
- * {logsnr_t, logsnr_s, x0_scale, x0_eps_coef, mean_z_coef, mean_x0_coef, std, 0}. */
+ * {logsnr_t, logsnr_s, x0_scale, x0_eps_coef, mean_z_coef, mean_x0_coef, std,
+ *  logsnr of the TRAIN schedule at t (model-output conversion)}. */
 int msd_get_schedule(const msd_model* m, float* host_out);
 
 /* Read an internal buffer as float (bf16 widened) into host memory, for tests.

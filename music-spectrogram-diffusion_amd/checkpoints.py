@@ -192,6 +192,15 @@ def load_t5x_checkpoint(path: str) -> Dict[str, np.ndarray]:
     target = _find_target(tree)
     if target is None:
       raise CheckpointError("no 'target' parameter tree in %s" % index)
+    # the reference reads train_state.step (inference.py:178-181), not the directory name: a renamed
+    # or copied checkpoint directory must still report the step it was saved at
+    try:
+      saved = _unchunk(tree['optimizer']['state']['step'])
+      if _is_ts_spec(saved):
+        saved = read_zarr_array(os.path.join(ckpt, _spec_path(saved)))
+      step = int(np.asarray(saved).reshape(-1)[0])
+    except (KeyError, TypeError, ValueError, IndexError):
+      pass   # older layouts without optimizer.state.step: keep the directory name
 
     def walk(node, prefix):
       node = _unchunk(node)

@@ -85,8 +85,14 @@ __global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
 // the load-time table (row i of `coef`, see msd_api: kCoef*).  Also advances the
 // device-side scan index so a captured graph can be replayed N times.
 // ---------------------------------------------------------------------------
+// Row i of the table (msd_api.hip build_coef_table).  "M*" = the same conversions evaluated at the
+// TRAIN schedule's log-SNR, which is where the reference converts the model output
+// (diffusion_utils.py:294), while CFG / clip / the sampler use the SAMPLER schedule (:411-412).
 enum { kCoefLogsnrT = 0, kCoefLogsnrS, kCoefX0Scale, kCoefX0Eps, kCoefMeanZ, kCoefMeanX0,
-       kCoefStd, kCoefEpsScale, kCoefEpsX0, kCoefAlphaS, kCoefSigmaS, kCoefPad, kCoefCount };
+       kCoefStd, kCoefEpsScale, kCoefEpsX0, kCoefAlphaS, kCoefSigmaS,
+       kCoefMLogsnr, kCoefMX0Scale, kCoefMX0Eps, kCoefMEpsScale, kCoefMEpsX0, kCoefMAlpha, kCoefMSigma,
+       kCoefPad0, kCoefPad1, kCoefCount };
+enum { kOutEps = 0, kOutX0 = 1, kOutV = 2 };   // = msd_model_output
 
 struct SamplerParams {
   const float* eps;     // [passes][n] decoder outputs (pass 0 = conditional)
@@ -99,9 +105,47 @@ struct SamplerParams {
   int passes;           // 2 with CFG
   float cond_wt;        // eval_condition_weight
   int clip_x0, ddim;
+  int model_output = kOutEps;   // what the network predicts (diffusion_utils.py:288-322)
   bf16_t* z_hi;         // optional bf16 planes of the new z (A operand of the next input projection)
   bf16_t* z_lo;
 };
+
+// model output -> (eps, x0) at the TRAIN schedule's log-SNR (diffusion_utils.py:288-322)
+__device__ __forceinline__ void convert_model_output(int mode, const float* c, float z, float o,
+                                                     float& eps, float& x0) {
+  if (mode == kOutEps) {
+    eps = o;
+    x0 = c[kCoefMX0Scale] * (z - o * c[kCoefMX0Eps]);
+  } else if (mode == kOutX0) {
+    x0 = o;
+    eps = c[kCoefMEpsScale] * (z - o * c[kCoefMEpsX0]);
+  } else {  // v: x0 = alpha z - sigma v
+    x0 = c[kCoefMAlpha] * z - c[kCoefMSigma] * o;
+    eps = c[kCoefMEpsScale] * (z - x0 * c[kCoefMEpsX0]);
+  }
+}
+
+// one element of eval_step.body after the decoder calls (diffusion_utils.py:416-452):
+// o_c / o_u = conditional / unconditional model output, nz = the step's normal draw
+__device__ __forceinline__ float sampler_update(const SamplerParams& p, const float* c, int i, float z,
+                                                float o_c, float o_u, float nz) {
+  float eps, x0;
+  convert_model_output(p.model_output, c, z, o_c, eps, x0);
+  if (p.passes == 2) {
+    float eps_u, x0_u;
+    convert_model_output(p.model_output, c, z, o_u, eps_u, x0_u);
+    eps = p.cond_wt * eps + (1.0f - p.cond_wt) * eps_u;
+    x0 = c[kCoefX0Scale] * (z - eps * c[kCoefX0Eps]);
+  }
+  if (p.clip_x0) {
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    eps = c[kCoefEpsScale] * (z - x0 * c[kCoefEpsX0]);
+  }
+  float zs;
+  if (p.ddim) zs = c[kCoefAlphaS] * x0 + c[kCoefSigmaS] * eps;
+  else zs = c[kCoefMeanZ] * z + c[kCoefMeanX0] * x0 + c[kCoefStd] * nz;
+  return (i == 0) ? x0 : zs;
+}
 
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   // step_from_slot1: the step's first kernel (in_proj) copied the index to slot 1 and nobody else
@@ -119,19 +163,7 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
     const float e1[4] = {eu.x, eu.y, eu.z, eu.w}, nn[4] = {nz.x, nz.y, nz.z, nz.w};
     float out[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float eps = e0[k];
-      if (p.passes == 2) eps = p.cond_wt * eps + (1.0f - p.cond_wt) * e1[k];
-      float x0 = c[kCoefX0Scale] * (zin[k] - eps * c[kCoefX0Eps]);
-      if (p.clip_x0) {
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-        eps = c[kCoefEpsScale] * (zin[k] - x0 * c[kCoefEpsX0]);
-      }
-      float zs;
-      if (p.ddim) zs = c[kCoefAlphaS] * x0 + c[kCoefSigmaS] * eps;
-      else zs = c[kCoefMeanZ] * zin[k] + c[kCoefMeanX0] * x0 + c[kCoefStd] * nn[k];
-      out[k] = (i == 0) ? x0 : zs;
-    }
+    for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zin[k], e0[k], e1[k], nn[k]);
     *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
     if (p.z_hi) {
       bf16_t h[4], l[4];

@@ -513,45 +513,112 @@ int pack_encoder(msd_model* m, hipStream_t s, const std::string& p, EncoderW& e)
 }
 
 // ---- step-indexed tables -------------------------------------------------------
-// diffusion_utils.py:166-187 (cosine), evaluated in float32 like the reference.
-float logsnr_cosine(float t) {
-  const float b = (float)std::atan(std::exp(-0.5 * 20.0));
-  const float a = (float)(std::atan(std::exp(0.5 * 20.0)) - std::atan(std::exp(-0.5 * 20.0)));
-  return -2.0f * std::log(std::tan(a * t + b));
-}
+// diffusion_utils.py:166-202, evaluated in float32 like the reference.  cosine: closed form;
+// linear: betas = linspace(start, stop, num_steps) in float64, log-SNR of the cumulative product
+// clipped to [-20, 20], then jnp.interp (float32) over linspace(0, 1, num_steps).
+struct Schedule {
+  int kind = MSD_SCHEDULE_COSINE;
+  std::vector<float> grid;   // linear: log-SNR at the num_steps knots
+  bool init(int k, double start, double stop, int n, std::string* err) {
+    kind = k;
+    if (k == MSD_SCHEDULE_COSINE) return true;
+    if (k != MSD_SCHEDULE_LINEAR) { *err = "Schedule not identified."; return false; }
+    if (n < 2) { *err = "linear schedule needs num_steps >= 2"; return false; }
+    if (!(start > 0.0) || !(stop < 1.0) || !(stop >= start)) { *err = "linear schedule needs 0 < start <= stop < 1"; return false; }
+    grid.resize(n);
+    double ac = 1.0;
+    for (int i = 0; i < n; ++i) {
+      const double beta = start + (stop - start) * (double)i / (double)(n - 1);
+      ac *= 1.0 - beta;
+      double l = std::log(ac) - std::log1p(-ac);
+      l = l < -20.0 ? -20.0 : (l > 20.0 ? 20.0 : l);
+      grid[i] = (float)l;
+    }
+    return true;
+  }
+  float at(float t) const {
+    if (kind == MSD_SCHEDULE_COSINE) {
+      const float b = (float)std::atan(std::exp(-0.5 * 20.0));
+      const float a = (float)(std::atan(std::exp(0.5 * 20.0)) - std::atan(std::exp(-0.5 * 20.0)));
+      return -2.0f * std::log(std::tan(a * t + b));
+    }
+    const int n = (int)grid.size();
+    auto xp = [&](int i) { return (float)((double)i / (double)(n - 1)); };
+    if (t <= xp(0)) return grid[0];
+    if (t >= xp(n - 1)) return grid[n - 1];
+    int i = 1;   // first knot strictly right of t (searchsorted side='right'), clipped to [1, n-1]
+    while (i < n - 1 && xp(i) <= t) ++i;
+    const float dx = xp(i) - xp(i - 1), df = grid[i] - grid[i - 1], delta = t - xp(i - 1);
+    return grid[i - 1] + (delta / dx) * df;
+  }
+};
 
-void build_coef_table(msd_model* m) {
-  const int N = m->N;
-  m->h_coef.assign((size_t)N * kCoefCount, 0.f);
+// One row of sampler coefficients per scan index (elementwise.h kCoef*): everything in
+// eval_step.body that depends only on i (diffusion_utils.py:408-452, 120-163, 205-233, 369-379).
+bool build_coef_rows(const msd_config& cfg, std::vector<float>* out, std::string* err) {
+  const int N = cfg.num_steps;
+  Schedule samp, train;
+  if (!samp.init(cfg.sampler_schedule, cfg.sampler_schedule_start, cfg.sampler_schedule_stop, N, err)) return false;
+  if (!train.init(cfg.train_schedule, cfg.train_schedule_start, cfg.train_schedule_stop,
+                  cfg.train_schedule_num_steps, err)) return false;
+  if (cfg.model_output < MSD_OUTPUT_EPS || cfg.model_output > MSD_OUTPUT_V) { *err = "Unknown model_output"; return false; }
+  if (cfg.logvar_type < MSD_LOGVAR_LARGE || cfg.logvar_type > MSD_LOGVAR_MEDIUM) { *err = "unknown logvar_type"; return false; }
+  if (cfg.logvar_type == MSD_LOGVAR_MEDIUM && !(cfg.logvar_frac >= 0.f && cfg.logvar_frac <= 1.f)) {
+    *err = "medium logvar fraction outside [0, 1]"; return false;
+  }
+  auto sigmoid = [](float x) { return 1.0f / (1.0f + std::exp(-x)); };
+  auto log_sigmoid = [](float x) { return -(std::fmax(-x, 0.0f) + std::log1p(std::exp(-std::fabs(x)))); };
+  out->assign((size_t)N * kCoefCount, 0.f);
   for (int i = 0; i < N; ++i) {
     const float t = ((float)i + 1.0f) / (float)N, s = (float)i / (float)N;
-    const float lt = logsnr_cosine(t), ls = logsnr_cosine(s);
-    float* c = &m->h_coef[(size_t)i * kCoefCount];
+    const float lt = samp.at(t), ls = samp.at(s), lm = train.at(t);
+    float* c = &(*out)[(size_t)i * kCoefCount];
     c[kCoefLogsnrT] = lt;
     c[kCoefLogsnrS] = ls;
     // predict_x0_from_eps (diffusion_utils.py:215-222)
     c[kCoefX0Scale] = std::sqrt(1.0f + std::exp(-lt));
     c[kCoefX0Eps] = 1.0f / std::sqrt(1.0f + std::exp(lt));
-    // diffusion_reverse (diffusion_utils.py:131-147), logvar_type "large"
+    // diffusion_reverse (diffusion_utils.py:120-163)
     const float alpha_st = std::sqrt((1.0f + std::exp(-lt)) / (1.0f + std::exp(-ls)));
-    const float alpha_s = std::sqrt(1.0f / (1.0f + std::exp(-ls)));
+    const float alpha_s = std::sqrt(sigmoid(ls));
     const float r = std::exp(lt - ls);
     const float one_minus_r = -std::expm1(lt - ls);
     c[kCoefMeanZ] = r * alpha_st;
     c[kCoefMeanX0] = one_minus_r * alpha_s;
-    c[kCoefStd] = std::sqrt(one_minus_r * (1.0f / (1.0f + std::exp(lt))));
+    if (cfg.logvar_type == MSD_LOGVAR_LARGE) {
+      c[kCoefStd] = std::sqrt(one_minus_r * sigmoid(-lt));
+    } else if (cfg.logvar_type == MSD_LOGVAR_SMALL) {
+      c[kCoefStd] = std::sqrt(one_minus_r * sigmoid(-ls));
+    } else {  // "medium:<frac>": interpolate the log-variances (log1mexp, diffusion_utils.py:100-106)
+      const float x = ls - lt;   // > 0
+      const float log_one_minus_r = x > std::log(2.0f) ? std::log1p(-std::exp(-x)) : std::log(-std::expm1(-x));
+      const float min_lv = log_one_minus_r + log_sigmoid(-ls), max_lv = log_one_minus_r + log_sigmoid(-lt);
+      c[kCoefStd] = std::sqrt(std::exp(cfg.logvar_frac * max_lv + (1.0f - cfg.logvar_frac) * min_lv));
+    }
     // predict_eps_from_x0 (diffusion_utils.py:205-212)
     c[kCoefEpsScale] = std::sqrt(1.0f + std::exp(lt));
     c[kCoefEpsX0] = 1.0f / std::sqrt(1.0f + std::exp(-lt));
     // ddim_step (diffusion_utils.py:376-378)
     c[kCoefAlphaS] = alpha_s;
-    c[kCoefSigmaS] = std::sqrt(1.0f / (1.0f + std::exp(ls)));
+    c[kCoefSigmaS] = std::sqrt(sigmoid(-ls));
+    // model-output conversion at the train schedule's log-SNR (diffusion_utils.py:294-317, 225-233)
+    c[kCoefMLogsnr] = lm;
+    c[kCoefMX0Scale] = std::sqrt(1.0f + std::exp(-lm));
+    c[kCoefMX0Eps] = 1.0f / std::sqrt(1.0f + std::exp(lm));
+    c[kCoefMEpsScale] = std::sqrt(1.0f + std::exp(lm));
+    c[kCoefMEpsX0] = 1.0f / std::sqrt(1.0f + std::exp(-lm));
+    c[kCoefMAlpha] = std::sqrt(sigmoid(lm));
+    c[kCoefMSigma] = std::sqrt(sigmoid(-lm));
   }
+  return true;
 }
 
 int build_tables(msd_model* m, hipStream_t s) {
   const int N = m->N, D = m->D;
-  build_coef_table(m);
+  {
+    std::string why;
+    if (!build_coef_rows(m->cfg, &m->h_coef, &why)) return fail(m, MSD_ERR_INVALID_ARGUMENT, "%s", why.c_str());
+  }
   HIP_TRY(m, hipMemcpyAsync(m->d_coef, m->h_coef.data(), m->h_coef.size() * sizeof(float),
                             hipMemcpyHostToDevice, s));
   // time embedding (diffusion_utils.py:69-97 via network.py:377-379), float32
@@ -929,6 +996,7 @@ void enqueue_step(Ctx& c, int batch) {
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
   sp.cond_wt = m->cfg.cfg_weight; sp.clip_x0 = m->cfg.clip_x0;
   sp.ddim = m->cfg.sampler == MSD_SAMPLER_DDIM;
+  sp.model_output = m->cfg.model_output;
   sp.z_hi = m->fold_norm ? m->zp.p[0] : nullptr;
   sp.z_lo = (m->fold_norm && m->NP == 2) ? m->zp.p[1] : nullptr;
   c.begin(KC_SAMPLER);
@@ -953,7 +1021,7 @@ void set_func_attrs() {
 // =============================================================================
 extern "C" {
 
-const char* msd_version(void) { return "msd_amd 0.1.0 (gfx950, abi 1)"; }
+const char* msd_version(void) { return "msd_amd 0.2.0 (gfx950, abi 2)"; }
 
 int msd_device_count(void) {
   int n = 0;
@@ -984,6 +1052,11 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->n_dims % 64) return bad("n_dims must be a multiple of 64");
   if (cfg->num_steps <= 0 || cfg->max_batch <= 0 || cfg->num_heads <= 0) return bad("non-positive size");
   if (cfg->has_context && cfg->context_length <= 0) return bad("context model needs context_length");
+  {  // schedule / model_output / logvar_type combinations are validated by building the table once
+    std::vector<float> rows;
+    std::string why;
+    if (!build_coef_rows(*cfg, &rows, &why)) { m->err = why; *out = m; return MSD_ERR_INVALID_ARGUMENT; }
+  }
   m->NP = cfg->precision == MSD_PREC_BF16X3 ? 2 : 1;
   m->D = cfg->emb_dim; m->H = cfg->num_heads; m->J = cfg->num_heads * kHeadDim; m->F = cfg->mlp_dim;
   m->T = cfg->targets_length; m->L = cfg->inputs_length; m->C = cfg->has_context ? cfg->context_length : 0;
@@ -993,7 +1066,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
-  m->S_pad = round_up(m->L + m->C, 64);
+  // encode_impl writes round_up(Lv, 64) token rows and then round_up(Cv, 64) context rows from row Lv
+  m->S_pad = round_up(m->L, 64) + round_up(m->C, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
   declare_weights(m);
   *out = m;
@@ -1304,7 +1378,7 @@ int msd_get_schedule(const msd_model* m, float* host_out) {
     const float* c = &m->h_coef[(size_t)i * kCoefCount];
     float* o = host_out + (size_t)i * 8;
     o[0] = c[kCoefLogsnrT]; o[1] = c[kCoefLogsnrS]; o[2] = c[kCoefX0Scale]; o[3] = c[kCoefX0Eps];
-    o[4] = c[kCoefMeanZ]; o[5] = c[kCoefMeanX0]; o[6] = c[kCoefStd]; o[7] = 0.f;
+    o[4] = c[kCoefMeanZ]; o[5] = c[kCoefMeanX0]; o[6] = c[kCoefStd]; o[7] = c[kCoefMLogsnr];
   }
   return MSD_OK;
 }

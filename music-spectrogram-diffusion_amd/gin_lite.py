@@ -93,9 +93,15 @@ def _logical_lines(text: str):
       continue
     if not buf:
       indent0 = len(line) - len(line.lstrip())
-    buf += (' ' if buf else '') + line.strip()
+    piece = line.strip()
+    # `gin.config_str()` wraps any binding longer than 80 columns with a trailing backslash
+    # ("a.b = \\" / "    @scope/c()"): the backslash continues the line and is not part of the value
+    continued = piece.endswith('\\')
+    if continued:
+      piece = piece[:-1].rstrip()
+    buf += (' ' if buf and piece else '') + piece
     depth = sum(buf.count(c) for c in '([{') - sum(buf.count(c) for c in ')]}')
-    if depth <= 0 and not buf.endswith('\\'):
+    if depth <= 0 and not continued:
       yield indent0, buf
       buf = ''
   if buf:
@@ -217,14 +223,14 @@ def model_spec_from_bindings(b: Dict[str, Any]) -> config_lib.ModelSpec:
   t5 = config_lib.T5Config(**fields)
 
   def schedule(scope, default):
-    name = _resolve(b, _lookup(b, 'DiffusionSchedule', 'name', scope))
-    if name is None:
-      return default
-    kw = {'name': name}
-    for p in ('start', 'stop', 'num_steps'):
+    kw = {}
+    for p in ('name', 'start', 'stop', 'num_steps'):
       v = _resolve(b, _lookup(b, 'DiffusionSchedule', p, scope))
       if v is not None:
         kw[p] = v
+    if not kw:
+      return default
+    kw.setdefault('name', default.name)
     return config_lib.DiffusionSchedule(**kw)
 
   sampler_defaults = config_lib.SamplerConfig()

@@ -16,10 +16,13 @@ The compute is the HIP library behind include/msd_amd.h (native.py); there is
 no fallback.  Differences that a caller can observe, all documented in
 DESIGN.md: (1) the RNG is the library's Philox generator, not jax threefry
 (pass ``init_z``/``noise`` for bit-identical noise across implementations);
-(2) ``checkpoint_path`` accepts ``None`` / ``'synthetic[:seed]'`` (scratch
-init with the reference initialisers, as ``from_checkpoint_or_scratch`` does
-without a checkpoint), a ``.safetensors`` / ``.npz`` flat dict, or an in-memory
-dict -- a T5X/zarr reader is SURVEY.md 8(f) N3.
+(2) ``checkpoint_path`` accepts a T5X checkpoint directory like the reference
+(checkpoints.py restates the flax-msgpack + zarr layout), and additionally
+``None`` / ``'synthetic[:seed]'`` (scratch init with the reference initialisers,
+as ``from_checkpoint_or_scratch`` does without a checkpoint), a ``.safetensors``
+/ ``.npz`` flat dict, or an in-memory dict.  MIDI / NoteSequence input goes
+through ``frontend/`` (``synthesize_midi``); ``.codec`` is the event codec the
+tokeniser uses (inference.py:108-111).
 """
 from __future__ import annotations
 
@@ -90,16 +93,29 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
     raise ValueError(f'Unknown context_positions: {t5.context_positions}')
   if d.sampler.name not in ('ddpm', 'ddim'):
     raise ValueError('Unknown sampler type: %s' % d.sampler.name)
-  if d.sampler.schedule.name != 'cosine' or d.train_schedule.name != 'cosine':
-    if d.sampler.schedule.name not in ('cosine', 'linear'):
-      raise ValueError('Schedule %s not identified.' % d.sampler.schedule.name)
-    raise NotImplementedError('only the cosine schedule (every shipped gin) is built')
-  if d.model_output != 'eps':
-    if d.model_output not in ('eps', 'x0', 'v', 'x0_and_eps'):
-      raise ValueError('Unknown model_output: %s' % d.model_output)
-    raise NotImplementedError('only model_output="eps" (the reference default) is built')
-  if d.sampler.logvar_type != 'large':
-    raise NotImplementedError('only logvar_type="large" (the reference default) is built')
+  for sched in (d.sampler.schedule, d.train_schedule):   # diffusion_utils.py:181-202
+    if sched.name not in native.SCHEDULES:
+      raise ValueError('Schedule %s not identified.' % sched.name)
+    if sched.name == 'linear' and (sched.start is None or sched.stop is None or not sched.num_steps):
+      raise ValueError('linear schedule needs start, stop and num_steps')
+  if d.model_output not in native.MODEL_OUTPUTS:       # diffusion_utils.py:288-322
+    if d.model_output == 'x0_and_eps':
+      raise NotImplementedError(
+          'model_output="x0_and_eps" splits a 2n-channel network output (diffusion_utils.py:306-311), '
+          "which the reference's own Decoder cannot produce (n_out = input channels, network.py:451-456)")
+    raise ValueError('Unknown model_output: %s' % d.model_output)
+  lv = d.sampler.logvar_type                            # diffusion_utils.py:141-157
+  lv_frac = 0.0
+  if lv == 'large':
+    lv_kind = native.MSD_LOGVAR_LARGE
+  elif lv == 'small':
+    lv_kind = native.MSD_LOGVAR_SMALL
+  elif lv.startswith('medium:'):
+    lv_kind, lv_frac = native.MSD_LOGVAR_MEDIUM, float(lv.split(':')[1])
+    if not 0 <= lv_frac <= 1:
+      raise ValueError('logvar_type medium:<frac> needs 0 <= frac <= 1')
+  else:
+    raise ValueError('Unknown logvar_type: %s' % lv)
   if precision not in native.PRECISIONS:
     raise ValueError('precision must be one of %s' % sorted(native.PRECISIONS))
   lens = spec.task_feature_lengths
@@ -126,6 +142,14 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
   cfg.cfg_weight = d.classifier_free_guidance.eval_condition_weight
   cfg.feature_min = codec.min_value
   cfg.feature_max = codec.max_value
+  cfg.model_output = native.MODEL_OUTPUTS[d.model_output]
+  cfg.logvar_type, cfg.logvar_frac = lv_kind, lv_frac
+  ss, ts = d.sampler.schedule, d.train_schedule
+  cfg.sampler_schedule = native.SCHEDULES[ss.name]
+  cfg.sampler_schedule_start, cfg.sampler_schedule_stop = float(ss.start or 0.0), float(ss.stop or 0.0)
+  cfg.train_schedule = native.SCHEDULES[ts.name]
+  cfg.train_schedule_start, cfg.train_schedule_stop = float(ts.start or 0.0), float(ts.stop or 0.0)
+  cfg.train_schedule_num_steps = int(ts.num_steps or 0)
   return cfg
 
 
@@ -192,7 +216,10 @@ class InferenceModel(object):
 
     self.model = _ModelInfo(spec)
     self.audio_codec = audio_codecs.get_codec(spec.audio_codec)
-    self.codec = None  # event codec (vocabularies.build_codec): tokeniser side, SURVEY 8(f) N1
+    # inference.py:104-111: the event codec of the tokeniser side, built from the gin's velocity bins
+    from .frontend import vocabularies
+    self.vocab_config = vocabularies.VocabularyConfig(num_velocity_bins=spec.num_velocity_bins)
+    self.codec = vocabularies.build_codec(self.vocab_config)
 
     if not torch.cuda.is_available():
       raise native.NativeLibraryError(
@@ -286,6 +313,10 @@ class InferenceModel(object):
       raise ValueError('batch %d exceeds batch_size %d' % (b, self.batch_size))
     t, n = self.targets_length, self.audio_codec.n_dims
     t0 = time.perf_counter()
+    with torch.cuda.device(dev):
+      # tensors the caller produced on its own stream (e.g. the previous prediction) are consumed on
+      # the model's stream: order the two
+      self._stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.device(dev), torch.cuda.stream(self._stream):
       s = self._stream.cuda_stream
       ctx = mask = None
@@ -295,6 +326,8 @@ class InferenceModel(object):
           raise ValueError('encoder_continuous_inputs must be [batch, %d, %d]'
                            % (self.targets_context_length, n))
         mask = np.ascontiguousarray(_to_numpy(batch['encoder_continuous_mask']), dtype=np.int32)
+        if mask.shape != (b, self.targets_context_length):   # msd_encode copies batch * C ints from it
+          raise ValueError('encoder_continuous_mask must be [batch, %d]' % self.targets_context_length)
       nm.encode(b, tokens, ctx, mask, stream=s)
       t1 = time.perf_counter()
       out = torch.empty((b, t, n), dtype=torch.float32, device=dev)

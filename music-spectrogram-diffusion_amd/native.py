@@ -42,14 +42,27 @@ class NativeLibraryError(RuntimeError):
   pass
 
 
+MSD_SCHEDULE_COSINE, MSD_SCHEDULE_LINEAR = 0, 1
+MSD_OUTPUT_EPS, MSD_OUTPUT_X0, MSD_OUTPUT_V = 0, 1, 2
+MSD_LOGVAR_LARGE, MSD_LOGVAR_SMALL, MSD_LOGVAR_MEDIUM = 0, 1, 2
+SCHEDULES = {'cosine': MSD_SCHEDULE_COSINE, 'linear': MSD_SCHEDULE_LINEAR}
+MODEL_OUTPUTS = {'eps': MSD_OUTPUT_EPS, 'x0': MSD_OUTPUT_X0, 'v': MSD_OUTPUT_V}
+
+
 class MsdConfig(ctypes.Structure):
+  """msd_config of include/msd_amd.h (ABI 2), field for field."""
   _fields_ = [(n, ctypes.c_int32) for n in (
       'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
       'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
       'targets_length', 'context_length', 'n_dims', 'num_steps', 'sampler', 'clip_x0',
       'context_terminal_relative', 'precision', 'max_batch')] + [
           (n, ctypes.c_float) for n in (
-              'max_decoder_noise_time', 'cfg_weight', 'feature_min', 'feature_max')]
+              'max_decoder_noise_time', 'cfg_weight', 'feature_min', 'feature_max')] + [
+      ('model_output', ctypes.c_int32), ('logvar_type', ctypes.c_int32), ('logvar_frac', ctypes.c_float),
+      ('sampler_schedule', ctypes.c_int32), ('sampler_schedule_start', ctypes.c_float),
+      ('sampler_schedule_stop', ctypes.c_float), ('train_schedule', ctypes.c_int32),
+      ('train_schedule_start', ctypes.c_float), ('train_schedule_stop', ctypes.c_float),
+      ('train_schedule_num_steps', ctypes.c_int32)]
 
 
 _lib = None

@@ -45,7 +45,7 @@ class FastModel:
   def __init__(self, xp, cfg, diffusion_config, params, context, precision='f32',
                codec=None):
     assert cfg.decoder_cross_attend_style == 'concat_encodings'
-    assert diffusion_config.model_output == 'eps'
+    assert diffusion_config.model_output in ('eps', 'x0', 'v')
     assert diffusion_config.sampler.name in ('ddpm', 'ddim')
     self.xp, self.cfg, self.dc = xp, cfg, diffusion_config
     self.context = context
@@ -236,11 +236,14 @@ class FastModel:
     for i in reversed(range(n)):
       lt = xp.reshape(self.logsnr_t[i], (1,))
       ls = xp.reshape(self.logsnr_s[i], (1,))
-      eps = self.decoder_pass(z, i, True)
-      x0 = du.predict_x0_from_eps(xp, z=z, eps=eps, logsnr=lt)
+      # the model output is converted at the TRAIN schedule's log-SNR (diffusion_utils.py:294)
+      tm = xp.full((1,), 0.0) + (float(i) + 1.0)
+      tm = tm / float(n)
+      o = du.get_x0_and_eps_from_model_output(xp, z, tm, self.decoder_pass(z, i, True), dc)
+      eps, x0 = o['eps'], o['x0']
       if w != 1:
-        eps_u = self.decoder_pass(z, i, False)
-        eps = w * eps + (1. - w) * eps_u
+        ou = du.get_x0_and_eps_from_model_output(xp, z, tm, self.decoder_pass(z, i, False), dc)
+        eps = w * eps + (1. - w) * ou['eps']
         x0 = du.predict_x0_from_eps(xp, z=z, eps=eps, logsnr=lt)
       if dc.sampler.clip_x0:
         x0 = xp.clip(x0, -1.0, 1.0)

@@ -13,6 +13,11 @@ holds only the expected mel output and the seeds.
   tiny_context_n6.npz        tiny_context preset, 6 steps, batch 2, ragged context
   small_n1000.npz            BASELINE config 2 shape: small/no-context, 1000 steps, 1 segment
   base_with_context_n1000.npz  BASELINE config 3 shape: 2 chained segments, 1000 steps
+  base_chain_n1000.npz       the same song continued to 6 chained segments (float64), plus the float32
+                             oracle's OWN chained run of the same song as the yardstick (`mel_f32`,
+                             per-segment `rms_f32`): how far the reference's arithmetic itself drifts
+                             along the chain.  Two processes: `chain64` and `chain32` (hours of CPU);
+                             `chainpack` merges them.  Saved after every segment.
 """
 import os
 import sys
@@ -42,11 +47,11 @@ def tiny():
                       weight_seed=3, jitter=0.1, batch_seed=7, noise_seed=11)
 
 
-def song(preset, n_segments, name, weight_seed=0, seed=0):
+def song(preset, n_segments, name, weight_seed=0, seed=0, dtype='float64', threads=None):
   spec = msd_amd.config.preset(preset, num_steps=1000)
   params = msd_amd.synthetic.init_params(spec, weight_seed)
   cfg, dc = helpers.oracle_configs(spec)
-  xp = backend.TorchBackend('float64', threads=os.cpu_count())
+  xp = backend.TorchBackend(dtype, threads=threads or os.cpu_count())
   fm = fast.FastModel(xp, cfg, dc, params, spec.has_context)
   t, n = spec.task_feature_lengths['targets'], 128
   c = spec.task_feature_lengths.get('targets_context')
@@ -63,8 +68,22 @@ def song(preset, n_segments, name, weight_seed=0, seed=0):
     pred = out
     outs.append(out)
     print('%s segment %d: %.0fs' % (name, k, time.time() - t0), flush=True)
-  np.savez_compressed(os.path.join(HERE, name), mel=np.concatenate(outs, 1), weight_seed=weight_seed,
-                      noise_seed=seed, n_segments=n_segments)
+    np.savez_compressed(os.path.join(HERE, name), mel=np.concatenate(outs, 1), weight_seed=weight_seed,
+                        noise_seed=seed, n_segments=k + 1)
+
+
+def chainpack():
+  """Merge the float64 chain and the float32 oracle's own chain into one fixture."""
+  a = np.load(os.path.join(HERE, '_chain64.npz'))
+  b = np.load(os.path.join(HERE, '_chain32.npz'))
+  n = min(int(a['n_segments']), int(b['n_segments']))
+  t = 256
+  m64, m32 = a['mel'][:, :n * t], b['mel'][:, :n * t]
+  rms32 = [helpers.rms(m32[:, k * t:(k + 1) * t], m64[:, k * t:(k + 1) * t]) for k in range(n)]
+  print('float32 oracle vs float64 oracle, per segment:', ' '.join('%.2e' % r for r in rms32))
+  np.savez_compressed(os.path.join(HERE, 'base_chain_n1000.npz'), mel=m64, mel_f32=m32,
+                      rms_f32=np.asarray(rms32), weight_seed=int(a['weight_seed']),
+                      noise_seed=int(a['noise_seed']), n_segments=n)
 
 
 if __name__ == '__main__':
@@ -75,3 +94,11 @@ if __name__ == '__main__':
     song('small', 1, 'small_n1000.npz')
   if 'base' in what:
     song('base_with_context', 2, 'base_with_context_n1000.npz')
+  nseg = int(os.environ.get('CHAIN_SEGMENTS', 6))
+  nthr = int(os.environ.get('CHAIN_THREADS', 0)) or None
+  if 'chain64' in what:
+    song('base_with_context', nseg, '_chain64.npz', dtype='float64', threads=nthr)
+  if 'chain32' in what:
+    song('base_with_context', nseg, '_chain32.npz', dtype='float32', threads=nthr)
+  if 'chainpack' in what:
+    chainpack()

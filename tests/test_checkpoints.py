@@ -86,6 +86,17 @@ def test_latest_step_and_errors(tmp_path):
     checkpoints.load_t5x_checkpoint(str(tmp_path / 'empty'))
 
 
+def test_step_comes_from_the_saved_train_state_not_the_directory_name(tmp_path):
+  """The reference reads train_state.step (inference.py:178-181): a renamed / copied checkpoint
+  directory keeps reporting the step it was saved at."""
+  import shutil
+  p = {'a/b': np.ones((2, 2), np.float32)}
+  ckpt = checkpoints.save_t5x_checkpoint(p, str(tmp_path / 'm'), step=1234)
+  shutil.move(ckpt, str(tmp_path / 'renamed_copy'))
+  got = checkpoints.load_t5x_checkpoint(str(tmp_path / 'renamed_copy'))
+  assert int(got['__step__']) == 1234
+
+
 def test_inference_loader_accepts_t5x_dir(tmp_path):
   """InferenceModel's restore path (reference inference.py:159-176 takes the checkpoint directory)."""
   from msd_amd import inference

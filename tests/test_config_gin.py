@@ -72,3 +72,36 @@ def test_shipped_gin_files_equal_typed_presets(model_gin, task_gin, preset):
       ["include '%s'" % os.path.join(REF_GIN, task_gin),
        "include '%s'" % os.path.join(REF_GIN, 'audio_codecs/melgan.gin')])
   assert gin_lite.model_spec_from_bindings(gin_lite.parse(cfg)) == config.preset(preset)
+
+
+def test_backslash_wrapped_bindings_as_config_str_emits_them():
+  """gin.config_str() wraps every binding longer than 80 columns as `key = \\` + an indented value
+  line; the continuation must yield the value (a Ref / dict / tuple), not the string '\\ ...'.  Uses a
+  non-default schedule scope so that no hard-coded fallback scope can hide a dropped reference."""
+  text = '''
+TASK_FEATURE_LENGTHS = \\
+    {'inputs': 2048, 'targets': 256}
+MODEL = \\
+    @models.DiffusionModel()
+AUDIO_CODEC = @audio_codecs.MelGAN()
+models.DiffusionModel.module = @network.Transformer()
+models.DiffusionModel.diffusion_config = \\
+    @diffusion_utils.DiffusionConfig()
+diffusion_utils.DiffusionConfig.sampler = @diffusion_utils.SamplerConfig()
+diffusion_utils.SamplerConfig.schedule = \\
+    @fast/diffusion_utils.DiffusionSchedule()
+fast/diffusion_utils.DiffusionSchedule.num_steps = 100
+network.T5Config.emb_dim = 512
+network.T5Config.num_heads = 6
+network.T5Config.mlp_dim = 1024
+network.T5Config.mlp_activations = \\
+    ('gelu', 'linear')
+network.T5Config.decoder_cross_attend_style = \\
+    'concat_encodings'
+'''
+  b = gin_lite.parse(text)
+  assert not any(isinstance(v, str) and v.startswith('\\') for v in b.values()), b
+  spec = gin_lite.model_spec_from_bindings(b)
+  assert spec.diffusion.sampler.schedule.num_steps == 100
+  assert spec.task_feature_lengths == {'inputs': 2048, 'targets': 256}
+  assert spec.t5.mlp_activations == ('gelu', 'linear') and spec.model == 'DiffusionModel'
