@@ -12,9 +12,17 @@ base_with_context, 1000-step DDPM, synthetic MIDI tokens, seeded synthetic
 weights.  The warm-up segments absorb the one-time restore/graph capture exactly
 like the reference excludes its first segment (beam/evaluation.py:217-220).
 
-N > 1: one process per GPU, every rank synthesizes its own song (song-parallel
-replicas, no collective on the data path: SURVEY.md 8(e)); value = frames of all
-ranks / max-over-ranks time ("weak" scaling).
+N > 1: one process per GPU.  --mode (sharding.py):
+  replicas   (default) every rank synthesizes its own song: no message on the data path
+  chained    ONE song of N*K segments cut into N contiguous chunks; rank r starts when rank r-1 hands
+             over its last prediction (one 128 KiB device-to-device message, RCCL send/recv = one xGMI
+             link).  Bit-identical to the sequential song; serial by construction (BASELINE config 4's
+             partitioning for a single song)
+  wavefront  K songs of N segments each, rank r runs segment r of every song while rank r-1 already
+             works on the next song: all ranks busy after N-1 fill steps (efficiency K / (K+N-1))
+  masked     one song of N*K segments, chunk heads run context-masked (no message, not parity-exact at
+             the N-1 cuts: the reference's own i == 0 / always_mask_context behaviour there)
+value = frames of all ranks / max-over-ranks time; per-GPU work is K segments in every mode ("weak").
 
 The JSON line also carries
   roofline      dominant kernel class: algorithmic FLOP per launch / mean launch
@@ -65,22 +73,66 @@ def class_flops(spec, s_valid: float, passes: int):
   }
 
 
-def pmc_traffic(kernel_class, args):
-  """Fabric-side bytes per launch of `kernel_class` from the committed PMC passes
-  (profiles/pmc_traffic.json, made by tools/prof_pmc.sh + tools/pmc_traffic.py on this same
-  command).  rocprofv3 cannot run inside the timed process, so the number is the committed
-  measurement; it only applies to the configuration it was taken on (else null)."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+def class_bytes(spec, s_valid: float, passes: int, planes: int = 2):
+  """ALGORITHMIC bytes per launch of each kernel class at batch 1: every operand read once, every
+  result written once (bf16 planes: 2 B x `planes`; fp32: 4 B).  What a launch must move if nothing
+  were fetched twice -- the denominator of the waste ratio against the PMC fabric traffic."""
+  t5 = spec.t5
+  d, h, f = t5.emb_dim, t5.num_heads, t5.mlp_dim
+  j = h * t5.head_dim
+  t = spec.task_feature_lengths['targets']
+  m = passes * t
+  pb = 2 * planes
+  fp = 4
+  return {
+      'gemm_qkv': pb * (m * d + 3 * j * d + m * 3 * j) + fp * (m * d // 32 + 3 * j),
+      'attn_self': pb * (m * 3 * j + m * j),
+      'gemm_attn_out': pb * (m * j + d * j + m * d) + fp * (2 * m * d + m * d // 32),
+      'gemm_cross_q': pb * (t * d + j * d + t * j) + fp * (t * d // 32),
+      'attn_cross': pb * (t * j + 2 * s_valid * j) + fp * 4 * (t * j + 2 * t * h),
+      'attn_cross_merge': fp * 4 * (t * j + 2 * t * h) + pb * t * j,
+      'gemm_cross_out': pb * (t * j + d * j + t * d) + fp * (2 * t * d + t * d // 32),
+      'gemm_mlp_in_geglu': pb * (m * d + 2 * f * d + m * f) + fp * (m * d // 32 + 2 * f),
+      'gemm_mlp_out': pb * (m * f + d * f + m * d) + fp * (2 * m * d + m * d // 32),
+      'final_proj_f32': fp * (m * d + d * 128 + m * 128),
+      'sampler_step': fp * (4 * t * 128) + pb * t * 128,
+      'in_proj_f32': pb * (t * 128 + d * 128 + m * d) + fp * (m * d + t * d),
+  }
+
+
+def library_hash():
+  """sha256 (first 16 hex) of the built HIP library: stamps which binary a profile was taken on."""
+  import hashlib
+  path = os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'csrc', 'libmsd_amd.so')
   if not os.path.exists(path):
-    return None, 'profiles/pmc_traffic.json not present'
+    return None
+  h = hashlib.sha256()
+  with open(path, 'rb') as f:
+    for chunk in iter(lambda: f.read(1 << 20), b''):
+      h.update(chunk)
+  return h.hexdigest()[:16]
+
+
+def profile_roofline(kernel_class, args):
+  """The committed rocprofv3 numbers for `kernel_class` (profiles/roofline.json, made by
+  tools/profile_round.sh + tools/make_roofline.py from a kernel-trace pass and separate PMC passes of
+  this same command): average duration, MFMA-pipe utilisation, fabric bytes.  rocprofv3 cannot run
+  inside the timed process, so these are the committed measurement; the entry carries the hash of the
+  library it was taken on and `matches_binary` says whether that is the binary being timed now."""
+  path = os.path.join(ROOT, 'profiles', 'roofline.json')
+  if not os.path.exists(path):
+    return None, 'profiles/roofline.json not present'
   if args.preset != 'base_with_context' or args.batch != 1 or args.precision != 'bf16x3' or args.cfg_weight == 1.0:
-    return None, 'PMC passes were taken on base_with_context, B=1, bf16x3, CFG'
+    return None, 'the profile was taken on base_with_context, B=1, bf16x3, CFG'
   with open(path) as f:
     t = json.load(f)
-  for cls, v in t['per_class'].items():
-    if kernel_class in cls.split('+'):
-      return v['bytes_per_launch'], 'bytes per launch, %s; %s' % (t['source'], t['correction'])
-  return None, 'class %s not in profiles/pmc_traffic.json' % kernel_class
+  cls = t.get('per_class', {}).get(kernel_class)
+  if cls is None:
+    return None, 'class %s not in profiles/roofline.json' % kernel_class
+  out = dict(cls)
+  out['profile_library_sha'] = t.get('library_sha')
+  out['matches_binary'] = t.get('library_sha') == library_hash()
+  return out, t.get('source', '')
 
 
 def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0):
@@ -120,12 +172,26 @@ def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0)
   t_step = (time.perf_counter() - t0) / sample_steps
   seg_s = t_enc + n_full * t_step
   return {
-      'value': t / seg_s, 'unit': 'mel-frames/sec', 'cores': cores, 'kind': 'port',
+      'value': t / seg_s, 'unit': 'mel-frames/sec', 'cores': cores, 'kind': 'port', 'reference_probe': probe_reference(),
       'xRTF': (t * 320 / 16000.0) / seg_s,
       'sample': 'torch-CPU float32 oracle (oracle/fast.py, cached cross K/V): encoders %.2fs + %d of %d '
                 'DDPM steps at %.3fs/step, extrapolated linearly to one %d-frame segment'
                 % (t_enc, sample_steps, n_full, t_step, t),
   }
+
+
+def probe_reference():
+  """time the real JAX/T5X reference on the host cores if its stack is importable on
+  this box; otherwise the oracle port stands in (kind "port").  The probe result is reported either way."""
+  missing = []
+  for mod in ('jax', 'flax', 't5x', 'gin', 'seqio'):
+    try:
+      __import__(mod)
+    except Exception:
+      missing.append(mod)
+  if missing:
+    return 'reference stack not importable here (missing: %s) -> oracle port timed instead' % ', '.join(missing)
+  return 'jax/flax/t5x importable, but the reference sources are not on this box (no /root/reference at run time)'
 
 
 def synthetic_midi_tokens(spec, seed, n_segments):
@@ -185,11 +251,47 @@ def batched_leg(spec, args):
           'note': 'same kernels, %d independent songs batched per handle; not the headline workload (SURVEY 8: B=1)' % nb}
 
 
+def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
+  """Untimed evidence that the hand-off primitive of --mode chained/wavefront works on this node: the
+  128 KiB context message goes rank r -> r+1 (device to device, dist.send/recv = RCCL point-to-point
+  over one xGMI link), `rounds` times down the chain; content checked, mean latency per hop reported."""
+  import torch
+  try:
+    buf = torch.full(shape, float(rank), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ok = True
+    t0 = time.perf_counter()
+    for k in range(rounds + 1):
+      if k == 1:   # round 0 opens the connections
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+      if rank > 0:
+        dist.recv(buf, src=rank - 1)
+        torch.cuda.synchronize()
+        ok = ok and bool((buf == float(rank - 1) + k).all())
+      if rank + 1 < world:
+        dist.send(torch.full(shape, float(rank) + k, dtype=torch.float32, device=device), dst=rank + 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {'ok': bool(flag.item() == 1.0), 'message_bytes': int(np.prod(shape)) * 4, 'hops': world - 1,
+            'us_per_hop': round(float(tt.item()) / rounds / max(world - 1, 1) * 1e6, 1),
+            'note': 'dist.send/recv of the device tensor (RCCL p2p); one message per chunk boundary in --mode chained'}
+  except Exception as e:  # never let the probe take the benchmark down
+    return {'ok': False, 'error': repr(e)[:200]}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5, help='timed segments')
+  ap.add_argument('--steps', type=int, default=5, help='timed segments (per GPU)')
   ap.add_argument('--warmup', type=int, default=1, help='untimed warm-up segments')
+  ap.add_argument('--mode', choices=['replicas', 'chained', 'wavefront', 'masked'], default='replicas',
+                  help='multi-GPU partitioning (module docstring); all modes equal replicas at --gpus 1')
   ap.add_argument('--preset', default='base_with_context')
   ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
   ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
@@ -206,6 +308,7 @@ def main():
 
   import torch
   import msd_amd
+  from msd_amd import sharding
 
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -225,17 +328,22 @@ def main():
   model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
   nb = args.batch
   t_frames = spec.task_feature_lengths['targets']
-  n_seg = args.warmup + args.steps
-  # every rank plays its own synthetic song (different token streams per rank)
-  if args.data == 'midi':
-    # a seeded synthetic multi-instrument MIDI song per (rank, song), through the real front end
-    # (frontend/: MIDI bytes -> notes -> the reference's segment tokens)
-    songs = [synthetic_midi_tokens(spec, 1000 * (rank * nb + b), n_seg) for b in range(nb)]
-    segs = [np.concatenate([songs[b][k] for b in range(nb)], 0) for k in range(n_seg)]
-  else:
-    segs = [np.concatenate([msd_amd.synthetic.segment_tokens(spec, 1000 * (rank * nb + b) + k) for b in range(nb)], 0)
-            for k in range(n_seg)]
   c_len = model.targets_context_length
+  mode = args.mode if (world > 1 and c_len is not None) else 'replicas'
+  if mode != 'replicas' and nb != 1:
+    raise SystemExit('--mode %s runs one song per rank at a time (--batch 1)' % mode)
+  n_seg = args.warmup + args.steps
+
+  def song_tokens(song, n):   # `nb` songs side by side -> list of [nb, L] segment inputs
+    if args.data == 'midi':
+      songs = [synthetic_midi_tokens(spec, 1000 * (song * nb + b), n) for b in range(nb)]
+      return [np.concatenate([songs[b][k] for b in range(nb)], 0) for k in range(n)]
+    return [np.concatenate([msd_amd.synthetic.segment_tokens(spec, 1000 * (song * nb + b) + k) for b in range(nb)], 0)
+            for k in range(n)]
+
+  # every rank warms up on its own song (restore, tables, graph capture: excluded like the reference
+  # excludes its first segment, beam/evaluation.py:217-220)
+  segs = song_tokens(rank, n_seg)
   pred = None
   if c_len is not None:
     pred = torch.zeros((nb, c_len, 128), dtype=torch.float32, device=model.device)
@@ -259,10 +367,24 @@ def main():
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   enc_s = smp_s = 0.0
-  for k in range(args.warmup, n_seg):
-    out = run_segment(k)
-    enc_s += model.last_timing['encode_s']
-    smp_s += model.last_timing['sample_s']
+  ctx_shape = (1, c_len or 0, 128)
+  if mode == 'replicas':
+    for k in range(args.warmup, n_seg):
+      out = run_segment(k)
+      enc_s += model.last_timing['encode_s']
+      smp_s += model.last_timing['sample_s']
+  elif mode == 'chained':      # one song, world * K segments, rank r owns [r K, (r+1) K)
+    song = [t[:1] for t in song_tokens(0, world * args.steps)]
+    out = sharding.chained_predict(model.predict_sequence, song, ctx_shape, rank, world,
+                                   comm_device=model.device, return_torch=True)
+  elif mode == 'wavefront':    # K songs of `world` segments: rank r runs segment r of every song
+    songs = [[t[:1] for t in song_tokens(j, world)] for j in range(args.steps)]
+    out = sharding.chained_wavefront(model.predict_sequence, songs, ctx_shape, rank, world,
+                                     comm_device=model.device, return_torch=True)[-1]
+  else:                        # masked: chunk heads context-masked, no message
+    song = [t[:1] for t in song_tokens(0, world * args.steps)]
+    a, b = sharding.contiguous_chunk(len(song), rank, world)
+    out = model.predict_sequence(song[a:b], first_segment_index=a, return_torch=True)
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
@@ -273,6 +395,7 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+  handoff = handoff_check(dist, rank, world, model.device, (1, c_len, 128)) if (dist is not None and c_len) else None
 
   result = None
   if rank == 0:
@@ -284,9 +407,13 @@ def main():
     nm = model._get_native()
     toks = segs[-1]
     s_valid = float((toks > 0).sum() / nb + (c_len or 0))
+    # make sure the profiled steps see this rank's last replica-style encode (chained modes end elsewhere)
+    if mode != 'replicas':
+      run_segment(n_seg - 1)
     with torch.cuda.device(model.device):
       prof = nm.profile_steps(nb, args.profile_steps, stream=model._stream.cuda_stream)
     flops = {k: v * nb for k, v in class_flops(spec, s_valid, passes).items()}
+    abytes = {k: v * nb for k, v in class_bytes(spec, s_valid, passes, 2 if args.precision == 'bf16x3' else 1).items()}
     per_class = {}
     for name, (ms, launches) in prof.items():
       if launches:
@@ -295,23 +422,42 @@ def main():
     # dominant kernel = the longest single launch of the step (the class whose template also has
     # the most algorithmic FLOPs); per-step totals by class are listed in per_class_ms_per_step
     dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_launch'])
-    achieved = flops[dom] / (per_class[dom]['ms_per_launch'] * 1e-3) / 1e12
+    event_ms = per_class[dom]['ms_per_launch']
     step_flops = sum(flops[n] * per_class[n]['launches_per_step'] for n in per_class if n in flops)
-    traffic, traffic_note = pmc_traffic(dom, args)
+    prof_entry, prof_src = profile_roofline(dom, args)
+    # `achieved` = algorithmic FLOP per launch / average launch duration.  Duration: the rocprofv3
+    # kernel-trace average of the committed profile when it was taken on THIS binary (what the graph
+    # replays), else the live hipEvent figure (eager launches, a little slower); both are reported.
+    use_prof = bool(prof_entry and prof_entry.get('matches_binary') and prof_entry.get('avg_us'))
+    dur_ms = prof_entry['avg_us'] * 1e-3 if use_prof else event_ms
+    achieved = flops[dom] / (dur_ms * 1e-3) / 1e12
+    graph_step_ms = (smp_s / args.steps / args.num_steps * 1e3) if mode == 'replicas' else None
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 5), 'traffic': traffic,
-        'traffic_note': traffic_note,
-        'kernel_ms_per_launch': round(per_class[dom]['ms_per_launch'], 5),
+        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 5),
+        'traffic': prof_entry.get('fabric_bytes_per_launch') if prof_entry else None,
+        'duration_source': 'rocprofv3 kernel-trace average (profiles/roofline.json, same binary)' if use_prof
+                           else 'hipEvents around eager launches (msd_profile_steps)',
+        'kernel_ms_per_launch': round(dur_ms, 5),
+        'kernel_ms_per_launch_hipevents': round(event_ms, 5),
+        'achieved_hipevents': round(flops[dom] / (event_ms * 1e-3) / 1e12, 3),
         'algorithmic_gflop_per_launch': round(flops[dom] / 1e9, 4),
+        'algorithmic_bytes_per_launch': int(abytes.get(dom, 0)),
+        'profile': prof_entry, 'profile_source': prof_src,
+        'library_sha': library_hash(),
         'whole_step': {
             'algorithmic_gflop': round(step_flops / 1e9, 2),
             'eager_ms': round(sum(v['ms_per_step'] for v in per_class.values()), 4),
-            'graph_ms': round(smp_s / args.steps / args.num_steps * 1e3, 4),
-            'achieved_tflops_graph': round(step_flops / (smp_s / args.steps / args.num_steps) / 1e12, 3),
+            'graph_ms': None if graph_step_ms is None else round(graph_step_ms, 4),
+            'achieved_tflops_graph': None if graph_step_ms is None else round(step_flops / (graph_step_ms * 1e-3) / 1e12, 3),
+            'launches': round(sum(v['launches_per_step'] for v in per_class.values()), 1),
         },
         'per_class_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in per_class.items()},
     }
+    par = {'replicas': 'song-parallel x%d' % world,
+           'chained': 'one song chained over %d GPUs (context hand-off, serial)' % world,
+           'wavefront': 'wavefront of %d songs x %d segments over %d GPUs (context hand-off per segment)' % (args.steps, world, world),
+           'masked': 'one song, %d masked-boundary chunks' % world}[mode]
     result = {
         'metric': 'mel-frames/sec', 'value': round(value, 3), 'unit': 'mel-frames/sec',
         'xRTF': round(audio_s / elapsed, 4),
@@ -322,16 +468,19 @@ def main():
                  if args.precision == 'bf16x3' else 'bf16',
         'data': ('synthetic (seeded tokens, reference-initialiser weights, Philox noise)' if args.data == 'tokens' else
                  'synthetic (seeded MIDI songs through the front end, reference-initialiser weights, Philox noise)'),
-        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, %s, %d segments of %d frames per song'
+        'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, %s, %d segments of %d frames per GPU'
                                % (args.preset, args.num_steps, args.cfg_weight, nb,
                                   'segment-sequential with context hand-off' if c_len is not None
                                   else 'independent segments (no context), one after the other',
                                   args.steps, t_frames),
-                   'precision': args.precision, 'parallelism': 'song-parallel x%d' % world},
-        'encode_ms_per_segment': round(enc_s / args.steps * 1e3, 3),
-        'sample_ms_per_segment': round(smp_s / args.steps * 1e3, 3),
+                   'precision': args.precision, 'parallelism': par, 'mode': mode},
         'roofline': roofline,
     }
+    if mode == 'replicas':
+      result['encode_ms_per_segment'] = round(enc_s / args.steps * 1e3, 3)
+      result['sample_ms_per_segment'] = round(smp_s / args.steps * 1e3, 3)
+    if handoff is not None:
+      result['handoff_check'] = handoff
     if world == 1 and args.batched_songs > 1 and nb == 1:
       result['batched'] = batched_leg(spec, args)
     if world == 1 and not args.no_cpu_baseline:

@@ -208,6 +208,43 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
                      const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
                      int heads, void* stream); /* q [n_q, heads*64] (n_q % 64 == 0), k/v [n_keys, heads*64] (n_keys % 32 == 0) */
 
+
+/* Standalone forms of the FUSED kernels of the step (each restates one reference function and has its
+ * own parity test against the oracle, tests/test_gpu_fused_ops.py).  All device pointers, fp32. */
+
+/* eval_step.body after the decoder calls (diffusion_utils.py:416-452): model-output conversion, CFG
+ * combine, x0 / clip / eps, ddpm_step (:382-395, diffusion_reverse :120-163) or ddim_step (:369-379).
+ * Uses cfg->{num_steps, sampler, clip_x0, cfg_weight, model_output, logvar_*, *_schedule*}.
+ *   out_uncond_dev may be NULL iff cfg_weight == 1; noise_dev (this step's draw) may be NULL (zeros). */
+int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_dev,
+                        const float* out_cond_dev, const float* out_uncond_dev,
+                        const float* noise_dev, float* z_out_dev, int64_t n, void* stream);
+
+/* x_out = x_in + a.w1 ; h_out = (RMSNorm(x_out; gamma) (.) (film_scale+1) + film_bias) . w2
+ * (layers.py:632-666 + the Dense that follows).  folded=1: the decoder's folded-norm epilogues
+ * (EpiResidualNorm producer, row-scale + tabulated bias.W consumer); folded=0: separate norm kernel.
+ * film_scale_dev / film_bias_dev [D] may both be NULL (plain RMSNorm).
+ *   x [m,d]  a [m,k]  w1 [k,d]  gamma [d]  w2 [d,n]  x_out [m,d]  h_out [m,n]; m,k,d,n % 64 == 0 */
+int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_dev,
+                              const float* w1_dev, const float* gamma_dev,
+                              const float* film_scale_dev, const float* film_bias_dev,
+                              const float* w2_dev, float* x_out_dev, float* h_out_dev,
+                              int m, int k, int d, int n, void* stream);
+
+/* MlpBlock's gated input (layers.py:483-497): out [m,f] = gelu_tanh(a.wi0) * (a.wi1) */
+int msd_op_geglu(const float* a_dev, const float* wi0_dev, const float* wi1_dev, float* out_dev,
+                 int m, int k, int f, void* stream);
+
+/* Fused q|k|v projection (layers.py:262-264) through the attention kernel's operand layouts (V^T with
+ * the per-16 key permutation, per segment of seg_len rows), returned un-permuted: q,k,v [m,j]. */
+int msd_op_qkv(const float* a_dev, const float* wq_dev, const float* wk_dev, const float* wv_dev,
+               float* q_out_dev, float* k_out_dev, float* v_out_dev, int m, int k, int j,
+               int seg_len, void* stream);
+
+/* decoder_norm + spec_out_dense in exact fp32 (network.py:445-456): out [m,n] = RMSNorm(x; gamma).w */
+int msd_op_final_proj(const float* x_dev, const float* gamma_dev, const float* w_dev, float* out_dev,
+                      int m, int d, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1471,6 +1471,7 @@ struct Scratch {
     void* q = nullptr;
     if (hipMalloc(&q, n * sizeof(Tp) + 16) != hipSuccess) return nullptr;
     (void)hipMemset(q, 0, n * sizeof(Tp) + 16);
+    (void)hipStreamSynchronize(nullptr);   // the ops run on the caller's (possibly non-blocking) stream
     p.push_back(q);
     return static_cast<Tp*>(q);
   }
@@ -1567,6 +1568,238 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
                      o.p[0], NP == 2 ? o.p[1] : (const bf16_t*)nullptr, o_dev, (int64_t)n_q * J);
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+
+// ---- standalone ops of the FUSED pieces (each has its own parity test, tests/test_gpu_fused_ops.py) ---
+extern "C++" {
+namespace {
+// W fp32 [K, N] (reference layout) -> packed W^T planes [N, K]
+bool pack_planes(Scratch& sc, const float* w_dev, int K, int N, int mode, int dst_row0, Planes* out, int rows,
+                 hipStream_t s) {
+  if (!out->p[0]) {
+    out->p[0] = sc.get<bf16_t>((size_t)rows * K);
+    out->p[1] = sc.get<bf16_t>((size_t)rows * K);
+    if (!out->p[0] || !out->p[1]) return false;
+  }
+  dim3 grid((K + 63) / 64, N), block(64);
+  hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, out->p[0], out->p[1], dst_row0, mode, 0);
+  return hipGetLastError() == hipSuccess;
+}
+bool split_new(Scratch& sc, const float* in, int64_t n, Planes* out, hipStream_t s) {
+  out->p[0] = sc.get<bf16_t>((size_t)n);
+  out->p[1] = sc.get<bf16_t>((size_t)n);
+  if (!out->p[0] || !out->p[1]) return false;
+  split(in, out->p[0], out->p[1], n, s);
+  return true;
+}
+void merge(const Planes& pl, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pl.p[0], pl.p[1], out, n);
+}
+}  // namespace
+}  // extern "C++"
+
+int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_dev, const float* out_cond_dev,
+                        const float* out_uncond_dev, const float* noise_dev, float* z_out_dev, int64_t n,
+                        void* stream) {
+  if (!cfg || cfg->struct_size != (int32_t)sizeof(msd_config) || !z_dev || !out_cond_dev || !z_out_dev ||
+      n <= 0 || n % 4 || step_index < 0 || step_index >= cfg->num_steps)
+    return MSD_ERR_INVALID_ARGUMENT;
+  const int passes = cfg->cfg_weight != 1.0f ? 2 : 1;
+  if (passes == 2 && !out_uncond_dev) return MSD_ERR_INVALID_ARGUMENT;
+  std::vector<float> rows;
+  std::string why;
+  if (!build_coef_rows(*cfg, &rows, &why)) return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  float* coef = sc.get<float>(rows.size());
+  float* eps = sc.get<float>((size_t)passes * n);
+  float* noise = sc.get<float>((size_t)n);   // one step's draw (zeros) when the caller gives none
+  const float** slot = sc.get<const float*>(1);
+  int* step = sc.get<int>(2);
+  if (!coef || !eps || !noise || !slot || !step) return MSD_ERR_HIP;
+  // the kernel indexes noise as base + i * n: hand it base = draw - i * n
+  const float* base = (noise_dev ? noise_dev : noise) - (size_t)step_index * n;
+  const int st[2] = {step_index, step_index};
+  if (hipMemcpyAsync(coef, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(eps, out_cond_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      (passes == 2 && hipMemcpyAsync(eps + n, out_uncond_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+      hipMemcpyAsync(z_out_dev, z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(slot, &base, sizeof(base), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(step, st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return MSD_ERR_HIP;
+  SamplerParams sp;
+  sp.eps = eps; sp.z = z_out_dev; sp.noise_slot = slot; sp.coef = coef; sp.step_ptr = step;
+  sp.n = (int)n; sp.passes = passes; sp.cond_wt = cfg->cfg_weight; sp.clip_x0 = cfg->clip_x0;
+  sp.ddim = cfg->sampler == MSD_SAMPLER_DDIM; sp.model_output = cfg->model_output;
+  sp.z_hi = nullptr; sp.z_lo = nullptr; sp.step_from_slot1 = 1;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, sp);
+  if (hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+// x_out = x_in + a . w1 ;  h_out = (RMSNorm(x_out; gamma) (.) (film_scale + 1) + film_bias) . w2
+// folded != 0: the product's path -- EpiResidualNorm (y = x (.) g planes + partial sums of squares)
+// then a consumer GEMM whose epilogue applies rstd and the tabulated bias.W2;
+// folded == 0: residual GEMM, rmsnorm_film_kernel, plain GEMM.
+int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_dev, const float* w1_dev,
+                              const float* gamma_dev, const float* film_scale_dev, const float* film_bias_dev,
+                              const float* w2_dev, float* x_out_dev, float* h_out_dev, int M, int K, int D, int N,
+                              void* stream) {
+  if (M % 64 || K % 64 || D % 64 || N % 64 || M <= 0 || D > 1024 || !x_in_dev || !a_dev || !w1_dev || !gamma_dev ||
+      !w2_dev || !x_out_dev || !h_out_dev || (!film_scale_dev) != (!film_bias_dev))
+    return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Planes a, w1, w2, y;
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, w1_dev, K, D, 0, 0, &w1, D, s) ||
+      !pack_planes(sc, w2_dev, D, N, 0, 0, &w2, N, s))
+    return MSD_ERR_HIP;
+  y.p[0] = sc.get<bf16_t>((size_t)M * D); y.p[1] = sc.get<bf16_t>((size_t)M * D);
+  const int tiles = D / kNarrowTile;
+  float* ssq = sc.get<float>((size_t)M * tiles);
+  float* film = sc.get<float>((size_t)2 * D);   // one-step, one-slot table: scale | bias
+  float* g = sc.get<float>((size_t)D);
+  float* bw = sc.get<float>((size_t)N);
+  int* step = sc.get<int>(2);
+  if (!y.p[0] || !y.p[1] || !ssq || !film || !g || !bw || !step) return MSD_ERR_HIP;
+  if (hipMemcpyAsync(x_out_dev, x_in_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return MSD_ERR_HIP;
+  if (film_scale_dev) {
+    (void)hipMemcpyAsync(film, film_scale_dev, D * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(film + D, film_bias_dev, D * sizeof(float), hipMemcpyDeviceToDevice, s);
+  }
+  hipError_t e = hipSuccess;
+  if (folded) {
+    hipLaunchKernelGGL(build_g_kernel, dim3((D + 255) / 256), dim3(256), 0, s, film, gamma_dev, g, 1, 1, 0, D);
+    GemmF32Params bp;   // bias . W2 : one row
+    bp.A = film + D; bp.B = w2_dev; bp.lda = D; bp.ldb = N; bp.M = 1; bp.N = N; bp.K = D;
+    e = launch_gemm_f32(bp, EpiF32Store{bw, N}, s);
+    EpiResidualNorm<2> er;
+    er.x = x_out_dev; er.ldx = D; er.y[0] = y.p[0]; er.y[1] = y.p[1]; er.ssq = ssq; er.tiles = tiles;
+    er.step_ptr = step; er.g_lo = g; er.g_lo_stride = 0; er.g_hi = g; er.g_hi_stride = 0; er.split_row = M / 2;
+    GemmParams p1 = gp<2>(a, K, w1, K, M, D, K);
+    p1.xcd_rows = 2; p1.xcd_walk_n = 1;
+    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 32, 32, 4>(p1, er, s);
+    EpiStoreF32 ef;
+    ef.out = h_out_dev; ef.ldc = N;
+    ef.rsc.ssq = ssq; ef.rsc.tiles = tiles; ef.rsc.inv_d = 1.0f / (float)D; ef.rsc.bias = bw;
+    ef.rsc.bias_step_stride = 0; ef.rsc.step_ptr = step;
+    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), ef, s);
+  } else {
+    e = launch_gemm_bf16_dma<2, 32, 32, 4>(gp<2>(a, K, w1, K, M, D, K), EpiResidual{x_out_dev, D}, s);
+    NormParams np;
+    np.x = x_out_dev; np.gamma = gamma_dev; np.film = film_scale_dev ? film : nullptr; np.step_ptr = step;
+    np.film_slots = 1; np.film_slot = 0; np.rows = M; np.D = D; np.out[0] = y.p[0]; np.out[1] = y.p[1]; np.out_f32 = nullptr;
+    hipLaunchKernelGGL((rmsnorm_film_kernel<1, 4>), dim3((M + 3) / 4), dim3(256), 0, s, np);
+    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), EpiStoreF32{h_out_dev, N}, s);
+  }
+  if (e != hipSuccess || hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+// out[M, F] = gelu_tanh(a . wi0) * (a . wi1)   (layers.py:483-497): interleaved wi_0/wi_1 packing + EpiGeglu,
+// on the 64 x 128 tile the decoder uses
+int msd_op_geglu(const float* a_dev, const float* wi0_dev, const float* wi1_dev, float* out_dev, int M, int K, int F,
+                 void* stream) {
+  if (M % 64 || K % 64 || F % 64 || M <= 0 || !a_dev || !wi0_dev || !wi1_dev || !out_dev) return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Planes a, wi, g;
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wi0_dev, K, F, 1, 0, &wi, 2 * F, s) ||
+      !pack_planes(sc, wi1_dev, K, F, 2, 0, &wi, 2 * F, s))
+    return MSD_ERR_HIP;
+  g.p[0] = sc.get<bf16_t>((size_t)M * F); g.p[1] = sc.get<bf16_t>((size_t)M * F);
+  if (!g.p[0] || !g.p[1]) return MSD_ERR_HIP;
+  EpiGeglu<2> eg;
+  eg.out[0] = g.p[0]; eg.out[1] = g.p[1]; eg.ldc = F;
+  hipError_t e = launch_gemm_bf16_dma<2, 64, 128, 3>(gp<2>(a, K, wi, K, M, 2 * F, K), eg, s);
+  if (e != hipSuccess) return MSD_ERR_HIP;
+  merge(g, out_dev, (int64_t)M * F, s);
+  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+}
+
+// Fused q|k|v projection with the attention kernel's operand layouts (EpiQKV): q, k row-major, V^T per
+// segment with the per-16 key permutation; returned un-permuted as q, k, v [M, J].
+int msd_op_qkv(const float* a_dev, const float* wq_dev, const float* wk_dev, const float* wv_dev, float* q_out_dev,
+               float* k_out_dev, float* v_out_dev, int M, int K, int J, int seg_len, void* stream) {
+  if (M % 64 || K % 64 || J % 64 || M <= 0 || seg_len <= 0 || seg_len % 64 || M % seg_len || !a_dev || !wq_dev ||
+      !wk_dev || !wv_dev || !q_out_dev || !k_out_dev || !v_out_dev)
+    return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Planes a, w, qk, vt;
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wq_dev, K, J, 0, 0, &w, 3 * J, s) ||
+      !pack_planes(sc, wk_dev, K, J, 0, J, &w, 3 * J, s) || !pack_planes(sc, wv_dev, K, J, 0, 2 * J, &w, 3 * J, s))
+    return MSD_ERR_HIP;
+  qk.p[0] = sc.get<bf16_t>((size_t)M * 2 * J); qk.p[1] = sc.get<bf16_t>((size_t)M * 2 * J);
+  vt.p[0] = sc.get<bf16_t>((size_t)M * J); vt.p[1] = sc.get<bf16_t>((size_t)M * J);
+  float* f32 = sc.get<float>((size_t)M * 2 * J);
+  if (!qk.p[0] || !qk.p[1] || !vt.p[0] || !vt.p[1] || !f32) return MSD_ERR_HIP;
+  EpiQKV<2> eq;
+  eq.qk[0] = qk.p[0]; eq.qk[1] = qk.p[1]; eq.vt[0] = vt.p[0]; eq.vt[1] = vt.p[1];
+  eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = seg_len; eq.vt_ld = seg_len; eq.vt_rows = J;
+  hipError_t e;
+  if ((3 * J) % 96 == 0 && (2 * J) % 96 == 0) e = launch_gemm_bf16_dma<2, 64, 96, 3>(gp<2>(a, K, w, K, M, 3 * J, K), eq, s);
+  else e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, 3 * J, K), eq, s);
+  if (e != hipSuccess) return MSD_ERR_HIP;
+  std::vector<float> h((size_t)M * 2 * J), qh((size_t)M * J), kh((size_t)M * J), vh((size_t)M * J);
+  merge(qk, f32, (int64_t)M * 2 * J, s);
+  if (hipMemcpyAsync(h.data(), f32, h.size() * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return MSD_ERR_HIP;
+  for (int m = 0; m < M; ++m)
+    for (int j = 0; j < J; ++j) {
+      qh[(size_t)m * J + j] = h[(size_t)m * 2 * J + j];
+      kh[(size_t)m * J + j] = h[(size_t)m * 2 * J + J + j];
+    }
+  merge(vt, f32, (int64_t)M * J, s);
+  if (hipMemcpyAsync(h.data(), f32, (size_t)M * J * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return MSD_ERR_HIP;
+  for (int m = 0; m < M; ++m) {   // V^T[seg][j][perm(key)] -> v[m][j]
+    const int seg = m / seg_len, key = m % seg_len, o16 = key & 15;
+    const int kp = (key & ~15) + 8 * ((o16 >> 2) & 1) + (o16 & 3) + 4 * (o16 >> 3);
+    for (int j = 0; j < J; ++j) vh[(size_t)m * J + j] = h[((size_t)seg * J + j) * seg_len + kp];
+  }
+  if (hipMemcpy(q_out_dev, qh.data(), qh.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(k_out_dev, kh.data(), kh.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(v_out_dev, vh.data(), vh.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return MSD_ERR_HIP;
+  return MSD_OK;
+}
+
+// out[M, n] = RMSNorm(x; gamma) . w in exact fp32 (network.py:445-456): final_proj_f32_kernel with the
+// decoder_norm folded in (w pre-multiplied by gamma, rstd from the partial sums of squares that the
+// residual epilogue of the last MLP writes -- produced here by the same epilogue with a zero update)
+int msd_op_final_proj(const float* x_dev, const float* gamma_dev, const float* w_dev, float* out_dev, int M, int D,
+                      int n, void* stream) {
+  if (M % 64 || D % 64 || n % 32 || M <= 0 || D > 1024 || !x_dev || !gamma_dev || !w_dev || !out_dev)
+    return MSD_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  const int tiles = D / kNarrowTile;
+  float* x = sc.get<float>((size_t)M * D);
+  float* ssq = sc.get<float>((size_t)M * tiles);
+  float* wg = sc.get<float>((size_t)D * n);
+  int* step = sc.get<int>(2);
+  Planes za, zw;   // zero operands of the zero-update residual GEMM
+  for (int i = 0; i < 2; ++i) { za.p[i] = sc.get<bf16_t>((size_t)M * 64); zw.p[i] = sc.get<bf16_t>((size_t)D * 64); }
+  if (!x || !ssq || !wg || !step || !za.p[1] || !zw.p[1]) return MSD_ERR_HIP;
+  if (hipMemcpyAsync(x, x_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return MSD_ERR_HIP;
+  EpiResidualNorm<2> er;
+  er.x = x; er.ldx = D; er.y[0] = nullptr; er.y[1] = nullptr; er.ssq = ssq; er.tiles = tiles; er.step_ptr = step;
+  er.g_lo = nullptr; er.g_lo_stride = 0; er.g_hi = nullptr; er.g_hi_stride = 0; er.split_row = 0;
+  hipError_t e = launch_gemm_bf16_dma<2, 32, 32, 4>(gp<2>(za, 64, zw, 64, M, D, 64), er, s);
+  if (e != hipSuccess) return MSD_ERR_HIP;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((D * n + 255) / 256), dim3(256), 0, s, w_dev, gamma_dev, wg, D, n);
+  FinalProjParams fp;
+  fp.x = x; fp.wg = wg; fp.ssq = ssq; fp.out = out_dev; fp.M = M; fp.N = n; fp.K = D; fp.tiles = tiles;
+  fp.inv_d = 1.0f / (float)D;
+  hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3((M / 16) * (n / 32)), dim3(64 * kFinalProjWaves), 0, s, fp);
+  if (hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
   return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
 }
 

@@ -365,15 +365,17 @@ class InferenceModel(object):
   # -- InferSong.process segment loop (beam/evaluation.py:161-223) ---------------------
   def predict_sequence(self, segments_tokens: Sequence[np.ndarray], seed: int = 0,
                        always_mask_context: bool = False, init_context: Optional[np.ndarray] = None,
-                       first_segment_index: int = 0, return_timing: bool = False, rng: str = 'philox'):
+                       first_segment_index: int = 0, return_timing: bool = False, rng: str = 'philox',
+                       return_torch: bool = False):
     """Synthesize a whole song: segments of int32 [inputs_length] (or [1, L]).
 
     Segment 0 runs with context zeros + mask 0 (beam/evaluation.py:195-198);
     segment i > 0 gets the previous PREDICTION (mel units) with mask 1
     (:194,199-205); ``always_mask_context`` masks every segment (:66-68).
-    ``init_context`` [1, C, n] (+ ``first_segment_index`` > 0) resumes a song in
-    the middle: the chained multi-GPU hand-off (sharding.py) uses it.
-    Returns float32 [1, T*K, n]; with ``return_timing`` also a dict with the
+    ``init_context`` [1, C, n] (NumPy or a device tensor; + ``first_segment_index`` > 0)
+    resumes a song in the middle: the chained multi-GPU hand-off (sharding.py) uses it.
+    Returns float32 [1, T*K, n] (NumPy; with ``return_torch`` the device tensor, so that the
+    hand-off message never leaves the GPU); with ``return_timing`` also a dict with the
     reference's own metric (evaluation.py:217-220,244-250).
     """
     torch = self._torch
@@ -400,7 +402,9 @@ class InferenceModel(object):
       if c_len is not None:
         pred = out[:1]
       outs.append(out[:1])
-    full = torch.cat(outs, dim=1).cpu().numpy()
+    full = torch.cat(outs, dim=1)
+    if not return_torch:
+      full = full.cpu().numpy()
     if not return_timing:
       return full
     seconds_per_chunk = self.targets_length * (self.audio_codec.hop_size / self.audio_codec.sample_rate)

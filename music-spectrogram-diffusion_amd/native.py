@@ -35,7 +35,8 @@ EXPORTED_SYMBOLS = (
     'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
     'msd_encode', 'msd_sample', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
     'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
-    'msd_op_attention')
+    'msd_op_attention', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
+    'msd_op_qkv', 'msd_op_final_proj')
 
 
 class NativeLibraryError(RuntimeError):
@@ -109,6 +110,11 @@ def load() -> ctypes.CDLL:
   lib.msd_op_gemm_bf16.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  lib.msd_op_sampler_step.argtypes = [c.POINTER(MsdConfig), i32, vp, vp, vp, vp, vp, i64, vp]
+  lib.msd_op_residual_norm_gemm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  lib.msd_op_geglu.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+  lib.msd_op_qkv.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  lib.msd_op_final_proj.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
   for name in EXPORTED_SYMBOLS:
     fn = getattr(lib, name)
     if name not in ('msd_version', 'msd_last_error', 'msd_destroy'):
@@ -287,3 +293,46 @@ def op_attention(precision: str, q, k, v, o, heads: int, n_keys_valid: Optional[
                             n_keys, nv, heads, stream)
   if rc:
     raise _EXC.get(rc, RuntimeError)('msd_op_attention failed (%d)' % rc)
+
+
+def _op_check(rc, what):
+  if rc:
+    raise _EXC.get(rc, RuntimeError)('%s failed (msd_status %d)' % (what, rc))
+
+
+def op_sampler_step(cfg: MsdConfig, step_index: int, z, out_cond, out_uncond, noise, z_out, stream: int = 0):
+  """One sampler update (msd_op_sampler_step).  Tensors: float32 device tensors of equal numel."""
+  lib = load()
+  cfg.struct_size = ctypes.sizeof(MsdConfig)
+  _op_check(lib.msd_op_sampler_step(ctypes.byref(cfg), step_index, _ptr(z), _ptr(out_cond), _ptr(out_uncond),
+                                    _ptr(noise), _ptr(z_out), z.numel(), stream), 'msd_op_sampler_step')
+
+
+def op_residual_norm_gemm(folded: bool, x_in, a, w1, gamma, film_scale, film_bias, w2, x_out, h_out,
+                          stream: int = 0):
+  lib = load()
+  m, k = a.shape
+  d, n = w2.shape
+  _op_check(lib.msd_op_residual_norm_gemm(int(bool(folded)), _ptr(x_in), _ptr(a), _ptr(w1), _ptr(gamma),
+                                          _ptr(film_scale), _ptr(film_bias), _ptr(w2), _ptr(x_out), _ptr(h_out),
+                                          m, k, d, n, stream), 'msd_op_residual_norm_gemm')
+
+
+def op_geglu(a, wi0, wi1, out, stream: int = 0):
+  lib = load()
+  m, k = a.shape
+  _op_check(lib.msd_op_geglu(_ptr(a), _ptr(wi0), _ptr(wi1), _ptr(out), m, k, wi0.shape[1], stream), 'msd_op_geglu')
+
+
+def op_qkv(a, wq, wk, wv, q, k_out, v, seg_len: int, stream: int = 0):
+  lib = load()
+  m, k = a.shape
+  _op_check(lib.msd_op_qkv(_ptr(a), _ptr(wq), _ptr(wk), _ptr(wv), _ptr(q), _ptr(k_out), _ptr(v), m, k,
+                           wq.shape[1], seg_len, stream), 'msd_op_qkv')
+
+
+def op_final_proj(x, gamma, w, out, stream: int = 0):
+  lib = load()
+  m, d = x.shape
+  _op_check(lib.msd_op_final_proj(_ptr(x), _ptr(gamma), _ptr(w), _ptr(out), m, d, w.shape[1], stream),
+            'msd_op_final_proj')

@@ -43,42 +43,56 @@ def _dist():
   return dist
 
 
-def _as_comm_tensor(torch, array, device):
-  return torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32)).to(device)
+def _on_device(comm_device) -> bool:
+  return str(comm_device) != 'cpu'
 
 
 def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.ndarray],
                     context_shape: Tuple[int, int, int], rank: int, world: int,
-                    comm_device='cpu', group=None, seed: int = 0, tag: int = 0) -> np.ndarray:
+                    comm_device='cpu', group=None, seed: int = 0, tag: int = 0,
+                    return_torch: bool = False):
   """Run this rank's contiguous chunk of ONE song with the context hand-off.
 
   predict_sequence: ``InferenceModel.predict_sequence``-compatible callable
-    ``(tokens_list, seed=, init_context=, first_segment_index=) -> [1, T*k, n]``.
+    ``(tokens_list, seed=, init_context=, first_segment_index=[, return_torch=]) -> [1, T*k, n]``.
   context_shape: (1, C, n) of the hand-off message.
-  Returns this rank's mel [1, T*k, n] (k = its number of segments, possibly 0 rows).
+  comm_device: 'cpu' (gloo; the message is staged through the host) or a cuda device: the message
+    is then received into, and sent from, device memory (``dist.send/recv`` of the device tensor =
+    RCCL point-to-point over one xGMI link) and ``predict_sequence`` is called with
+    ``return_torch=True`` so that the previous prediction never leaves the GPU.
+  Returns this rank's mel [1, T*k, n] (k = its number of segments, possibly 0 rows): NumPy, or the
+  device tensor with ``return_torch``.
   """
   import torch
   dist = _dist()
+  dev = _on_device(comm_device)
   start, stop = contiguous_chunk(len(segments_tokens), rank, world)
   init_context = None
   if rank > 0 and 0 < start < len(segments_tokens):  # mirrors the sender's condition
     buf = torch.empty(context_shape, dtype=torch.float32, device=comm_device)
     dist.recv(buf, src=rank - 1, group=group, tag=tag)
-    init_context = buf.cpu().numpy()
+    init_context = buf if dev else buf.numpy()
   mine = list(segments_tokens[start:stop])
   n = context_shape[2]
+  kw = {'return_torch': True} if dev else {}
   if mine:
-    out = predict_sequence(mine, seed=seed, init_context=init_context, first_segment_index=start)
-    out = np.asarray(out, np.float32)
+    out = predict_sequence(mine, seed=seed, init_context=init_context, first_segment_index=start, **kw)
+    if not dev:
+      out = np.asarray(out, np.float32)
   else:
-    out = np.zeros((1, 0, n), np.float32)
+    out = torch.zeros((1, 0, n), dtype=torch.float32, device=comm_device) if dev else np.zeros((1, 0, n), np.float32)
   if rank + 1 < world and stop < len(segments_tokens):
     c = context_shape[1]
     if mine:
       last = out[:, -c:, :]
     else:  # empty chunk: forward what we received
-      last = init_context if init_context is not None else np.zeros(context_shape, np.float32)
-    dist.send(_as_comm_tensor(torch, last, comm_device), dst=rank + 1, group=group, tag=tag)
+      last = init_context if init_context is not None else (
+          torch.zeros(context_shape, dtype=torch.float32, device=comm_device) if dev
+          else np.zeros(context_shape, np.float32))
+    msg = last.contiguous() if dev else torch.as_tensor(np.ascontiguousarray(last, dtype=np.float32))
+    dist.send(msg, dst=rank + 1, group=group, tag=tag)
+  if dev and not return_torch:
+    return out.cpu().numpy()
   return out
 
 
@@ -95,7 +109,7 @@ def masked_boundary_predict(predict_sequence: Callable, segments_tokens: Sequenc
 
 def chained_wavefront(predict_sequence: Callable, songs: Sequence[Sequence[np.ndarray]],
                       context_shape: Tuple[int, int, int], rank: int, world: int,
-                      comm_device='cpu', group=None, seed: int = 0) -> List[np.ndarray]:
+                      comm_device='cpu', group=None, seed: int = 0, return_torch: bool = False) -> List:
   """Every song chained over all ranks; rank r works on song j's chunk r while
   rank r-1 already works on song j+1's chunk r-1 (a pipeline wavefront), so all
   ranks are busy after ``world - 1`` fill steps.  Returns this rank's chunk of
@@ -103,7 +117,8 @@ def chained_wavefront(predict_sequence: Callable, songs: Sequence[Sequence[np.nd
   outs = []
   for j, song in enumerate(songs):
     outs.append(chained_predict(predict_sequence, song, context_shape, rank, world,
-                                comm_device=comm_device, group=group, seed=seed + j, tag=j))
+                                comm_device=comm_device, group=group, seed=seed + j, tag=j,
+                                return_torch=return_torch))
   return outs
 
 

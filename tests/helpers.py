@@ -12,14 +12,17 @@ T5_FIELDS = ['vocab_size', 'emb_dim', 'num_heads', 'num_encoder_layers', 'num_de
 def oracle_configs(spec):
   t5 = net.T5Config(**{k: getattr(spec.t5, k) for k in T5_FIELDS})
   d = spec.diffusion
+
+  def sched(x):
+    return sampler.DiffusionSchedule(x.name, start=x.start, stop=x.stop, num_steps=x.num_steps)
+
   dc = sampler.DiffusionConfig(
-      model_output=d.model_output,
+      model_output=d.model_output, train_schedule=sched(d.train_schedule),
       classifier_free_guidance=sampler.ClassifierFreeGuidanceConfig(
           eval_condition_weight=d.classifier_free_guidance.eval_condition_weight),
       sampler=sampler.SamplerConfig(
           name=d.sampler.name, clip_x0=d.sampler.clip_x0, logvar_type=d.sampler.logvar_type,
-          schedule=sampler.DiffusionSchedule(d.sampler.schedule.name,
-                                             num_steps=d.sampler.schedule.num_steps)))
+          schedule=sched(d.sampler.schedule)))
   return t5, dc
 
 
@@ -77,8 +80,8 @@ def assert_fp32_class(got, ref64, ref32, what=''):
   out_dev, out_f32 = float((e_dev > 1e-2).mean()), float((e_f32 > 1e-2).mean())
   print('%s median |err| device %.2e / f32-oracle %.2e; outliers(>1e-2) device %.4f / f32-oracle %.4f; rms %.2e / %.2e'
         % (what, med_dev, med_f32, out_dev, out_f32, rms(got, ref64), rms(ref32, ref64)))
-  assert med_dev <= 3 * med_f32 + 2e-6, 'bulk error is not fp32-class'
-  # bf16x3 products carry ~2^-16 relative error against float32's 2^-24, so more marginal
-  # elements flip at the clip boundary of the first steps; tests/diag/diag_fold_ab.py shows the
-  # same device paths agreeing to 1e-5 relative once clipping is off.
-  assert out_dev <= 4 * out_f32 + 2e-2, 'too many outliers'
+  assert med_dev <= 2 * med_f32 + 1e-6, 'bulk error is not fp32-class'
+  # Outliers: at most twice the float32 oracle's own count plus 0.1 % of the elements (bf16x3 products
+  # carry ~2^-16 relative error against float32's 2^-24, so a few more marginal elements flip at the
+  # clip boundary of the first steps; measured on the MI355X: 0.0000 .. 0.0003 against 0.0001).
+  assert out_dev <= 2 * out_f32 + 1e-3, 'too many outliers'

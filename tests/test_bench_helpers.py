@@ -26,14 +26,30 @@ def test_class_flops_match_design_table():
   assert 100e9 < total < 130e9                                      # ~112-121 GFLOP per step
 
 
-def test_pmc_traffic_only_for_the_measured_configuration():
+def test_class_bytes_match_the_hand_count():
+  """MLP-in at base, CFG, bf16x3: 12.6 MB weight planes + 1.6 MB activations + 4.2 MB output."""
+  spec = msd_amd.config.preset('base_with_context')
+  b = bench.class_bytes(spec, 2304.0, 2)
+  assert abs(b['gemm_mlp_in_geglu'] - (4 * 4096 * 768 + 4 * 512 * 768 + 4 * 512 * 2048)) < 0.1e6
+  assert b['attn_cross'] > b['attn_self']
+  one = bench.class_bytes(spec, 2304.0, 2, planes=1)
+  assert one['gemm_qkv'] < b['gemm_qkv']
+
+
+def test_profile_roofline_lookup_and_staleness_stamp():
+  """profiles/roofline.json (tools/make_roofline.py): per-class rocprof duration, MFMA utilisation and fabric
+  bytes, stamped with the library hash; only for the configuration it was measured on."""
   ok = argparse.Namespace(preset='base_with_context', batch=1, precision='bf16x3', cfg_weight=5.0)
-  val, note = bench.pmc_traffic('gemm_mlp_in_geglu', ok)
-  assert isinstance(val, int) and 10e6 < val < 100e6 and 'FETCH_SIZE' in note
+  e, src = bench.profile_roofline('gemm_mlp_in_geglu', ok)
+  assert e is not None and 'rocprofv3' in src
+  assert 5.0 < e['avg_us'] < 40.0 and 0.0 < e['mfma_util'] < 1.0 and e['waste'] >= 1.0
+  assert 10e6 < e['fabric_bytes_per_launch'] < 100e6
+  assert isinstance(e['matches_binary'], bool) and 'profile_library_sha' in e
   for other in (dict(preset='small'), dict(batch=8), dict(precision='bf16'), dict(cfg_weight=1.0)):
     ns = argparse.Namespace(**{**vars(ok), **other})
-    assert bench.pmc_traffic('gemm_mlp_in_geglu', ns)[0] is None
-  assert bench.pmc_traffic('no_such_class', ok)[0] is None
+    assert bench.profile_roofline('gemm_mlp_in_geglu', ns)[0] is None
+  assert bench.profile_roofline('no_such_class', ok)[0] is None
+  assert bench.library_hash() is None or len(bench.library_hash()) == 16
 
 
 def test_synthetic_midi_workload():

@@ -1,0 +1,260 @@
+"""-m gpu: the FUSED kernels of the DDPM step, one at a time, through the C-ABI against the oracle.
+
+These are the pieces that carry the tricky algebra and that whole-decoder tests would only see through
+2e-4-relative end results:
+  * sampler_step_kernel            vs oracle/sampler.py eval_step   (diffusion_utils.py:369-452), <= 1e-6
+  * folded RMSNorm + FiLM epilogues vs oracle/ops.py rms_layer_norm + FiLM (layers.py:632-666), and vs the
+    unfolded kernel path
+  * EpiGeglu (interleaved wi_0/wi_1, v_exp/v_rcp GELU)  vs oracle/ops.py gelu_tanh (layers.py:483-497)
+  * EpiQKV (q|k row-major, V^T with the per-16 key permutation)  vs a float64 matmul
+  * final_proj_f32_kernel (decoder_norm folded, exact fp32)      vs oracle rms_layer_norm + matmul
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+  import torch
+  import msd_amd
+  assert torch.cuda.is_available(), 'these tests need the MI355X'
+  msd_amd.native.load()
+  return torch, msd_amd.native
+
+
+def _dev(torch, a):
+  return torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def _relmax(got, ref):
+  return float(np.abs(np.asarray(got, np.float64) - ref).max() / np.abs(ref).max())
+
+
+# --------------------------------------------------------------------------------------------------
+# sampler
+# --------------------------------------------------------------------------------------------------
+def _sampler_spec(sampler='ddpm', model_output='eps', logvar='large', schedule='cosine', train='cosine',
+                  cfg_weight=5.0, clip=True, steps=50):
+  import msd_amd
+  from msd_amd import config as C
+  spec = msd_amd.config.preset('tiny', num_steps=steps, cfg_weight=cfg_weight)
+  d = spec.diffusion
+  ss = C.DiffusionSchedule(schedule, start=1e-4 if schedule == 'linear' else None,
+                           stop=2e-2 if schedule == 'linear' else None, num_steps=steps)
+  ts = C.DiffusionSchedule(train, start=2e-4 if train == 'linear' else None,
+                           stop=3e-2 if train == 'linear' else None, num_steps=80 if train == 'linear' else None)
+  d = dataclasses.replace(d, model_output=model_output, train_schedule=ts,
+                          sampler=dataclasses.replace(d.sampler, name=sampler, logvar_type=logvar, clip_x0=clip,
+                                                      schedule=ss))
+  return dataclasses.replace(spec, diffusion=d)
+
+
+CASES = [
+    dict(),                                                   # the shipped configuration: DDPM, eps, large, CFG 5
+    dict(cfg_weight=1.0),                                     # single pass
+    dict(sampler='ddim'),
+    dict(sampler='ddim', clip=False, cfg_weight=1.0),         # pred_eps straight from the conversion
+    dict(clip=False),
+    dict(model_output='x0'),
+    dict(model_output='v'),
+    dict(model_output='v', cfg_weight=1.0, clip=False),
+    dict(logvar='small'),
+    dict(logvar='medium:0.3'),
+    dict(schedule='linear'),
+    dict(schedule='linear', train='linear', model_output='x0'),   # conversion at a DIFFERENT log-SNR than the sampler's
+    dict(train='linear', model_output='v', sampler='ddim'),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: ','.join('%s=%s' % kv for kv in c.items()) or 'default')
+def test_sampler_step_vs_oracle(env, case):
+  """Every branch of eval_step.body, at the first (i = N-1, gain 22026), a middle, the second-to-last
+  and the last (i == 0 -> returns x0) scan index; float32 oracle on the same inputs, <= 1e-6."""
+  torch, native = env
+  import msd_amd
+  from msd_amd import inference
+  from oracle import backend, sampler
+  from tests import helpers
+  spec = _sampler_spec(**case)
+  cfg = inference._to_native_config(spec, msd_amd.audio_codecs.MelGAN(), 1, 'bf16x3')
+  _, dc = helpers.oracle_configs(spec)
+  steps = dc.sampler.schedule.num_steps
+  xp32, xp64 = backend.NumpyBackend('float32'), backend.NumpyBackend('float64')
+  rng = np.random.default_rng(5)
+  shape = (1, 8, 128)
+  worst = 0.0
+  for i in (steps - 1, steps // 2, 1, 0):
+    # keep z on the scale the chain has at this index so that clipping is exercised but not everything clips
+    z = rng.standard_normal(shape).astype(np.float32)
+    oc = rng.standard_normal(shape).astype(np.float32)
+    ou = rng.standard_normal(shape).astype(np.float32)
+    nz = rng.standard_normal(shape).astype(np.float32)
+    if i > steps // 2 and dc.model_output == 'eps':
+      oc = z + 1e-5 * oc   # at logsnr ~ -20 only eps ~ z leaves x0 inside [-1, 1]
+      ou = z + 1e-5 * ou
+    outs = {}
+    for name, xp in (('f32', xp32), ('f64', xp64)):
+      noise = [None] * steps
+      noise[i] = xp.asarray(nz)
+      pred = lambda z, time, include_conditioning, _xp=xp: _xp.asarray(oc if include_conditioning else ou)
+      body = sampler.eval_step(xp, noise, dc, 1, pred)
+      outs[name] = np.asarray(body(xp.asarray(z), i), np.float64)
+    got = torch.empty(shape, dtype=torch.float32, device='cuda')
+    native.op_sampler_step(cfg, i, _dev(torch, z), _dev(torch, oc),
+                           _dev(torch, ou) if dc.classifier_free_guidance.eval_condition_weight != 1 else None,
+                           _dev(torch, nz), got)
+    got = got.cpu().numpy().astype(np.float64)
+    # yardstick: float32 evaluation of the same formulas (the reference's arithmetic) vs float64
+    scale = max(1.0, float(np.abs(outs['f64']).max()))
+    e_dev = np.abs(got - outs['f64']).max() / scale
+    e_f32 = np.abs(outs['f32'] - outs['f64']).max() / scale
+    worst = max(worst, e_dev)
+    assert e_dev <= 1e-6 + 4 * e_f32, (i, e_dev, e_f32)
+    if i == 0:   # the last step returns the (clipped) x0
+      if dc.sampler.clip_x0:
+        assert np.abs(got).max() <= 1.0
+  print('sampler %s: worst scaled error %.2e' % (case, worst))
+
+
+def test_schedule_table_linear_and_cosine_vs_oracle(env):
+  """get_logsnr_t (diffusion_utils.py:166-202) for both schedule kinds, sampler and train side."""
+  torch, native = env
+  import msd_amd
+  from oracle import backend, sampler
+  xp = backend.NumpyBackend('float64')
+  for case in (dict(), dict(schedule='linear', train='linear')):
+    spec = _sampler_spec(steps=40, **case)
+    model = msd_amd.InferenceModel('synthetic:0', spec)
+    tab = model._get_native().schedule()
+    n = 40
+    t = (np.arange(n) + 1.0) / n
+    s = np.arange(n) / n
+    d = spec.diffusion
+    ss = sampler.DiffusionSchedule(d.sampler.schedule.name, d.sampler.schedule.start, d.sampler.schedule.stop, n)
+    ts = sampler.DiffusionSchedule(d.train_schedule.name, d.train_schedule.start, d.train_schedule.stop,
+                                   d.train_schedule.num_steps)
+    np.testing.assert_allclose(tab[:, 0], sampler.get_logsnr_t(xp, t, ss), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tab[:, 1], sampler.get_logsnr_t(xp, s, ss), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tab[:, 7], sampler.get_logsnr_t(xp, t, ts), rtol=2e-5, atol=2e-5)
+
+
+# --------------------------------------------------------------------------------------------------
+# folded RMSNorm + FiLM
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('film', [True, False])
+@pytest.mark.parametrize('m,k,d,n', [(128, 128, 256, 192), (512, 768, 768, 2304), (256, 2048, 768, 768)])
+def test_folded_norm_film_vs_oracle_and_unfolded(env, film, m, k, d, n):
+  torch, native = env
+  from oracle import backend, ops
+  xp = backend.NumpyBackend('float64')
+  rng = np.random.default_rng(m + k + d + n)
+  x_in = (3.0 * rng.standard_normal((m, d))).astype(np.float32)
+  x_in[:, ::7] *= 20.0   # a few dominant channels, like a trained residual stream
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w1 = (rng.standard_normal((k, d)) / np.sqrt(k)).astype(np.float32)
+  gamma = (1.0 + 0.3 * rng.standard_normal(d)).astype(np.float32)
+  sc = (0.5 * rng.standard_normal(d)).astype(np.float32) if film else None
+  bi = (0.5 * rng.standard_normal(d)).astype(np.float32) if film else None
+  w2 = (rng.standard_normal((d, n)) / np.sqrt(d)).astype(np.float32)
+  # oracle (float64): layers.py:632-649 then 664-665 then the Dense
+  x_ref = x_in.astype(np.float64) + a.astype(np.float64) @ w1.astype(np.float64)
+  h = ops.rms_layer_norm(xp, x_ref, gamma.astype(np.float64))
+  if film:
+    h = h * (sc.astype(np.float64) + 1.0) + bi.astype(np.float64)
+  h_ref = h @ w2.astype(np.float64)
+  res = {}
+  for folded in (True, False):
+    x_out = torch.empty((m, d), dtype=torch.float32, device='cuda')
+    h_out = torch.empty((m, n), dtype=torch.float32, device='cuda')
+    native.op_residual_norm_gemm(folded, _dev(torch, x_in), _dev(torch, a), _dev(torch, w1), _dev(torch, gamma),
+                                 None if sc is None else _dev(torch, sc), None if bi is None else _dev(torch, bi),
+                                 _dev(torch, w2), x_out, h_out)
+    res[folded] = (x_out.cpu().numpy(), h_out.cpu().numpy())
+    ex, eh = _relmax(res[folded][0], x_ref), _relmax(res[folded][1], h_ref)
+    print('folded=%s film=%s [%d,%d,%d,%d]: x %.2e  h %.2e' % (folded, film, m, k, d, n, ex, eh))
+    assert ex < 2e-5 and eh < 4e-5
+  # the fp32 residual stream is the same arithmetic on both paths
+  np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-5 * np.abs(x_ref).max())
+
+
+# --------------------------------------------------------------------------------------------------
+# gated GELU
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('m,k,f', [(64, 64, 64), (512, 768, 2048), (128, 512, 1024)])
+def test_geglu_vs_oracle(env, m, k, f):
+  torch, native = env
+  from oracle import backend, ops
+  xp = backend.NumpyBackend('float64')
+  rng = np.random.default_rng(m + k + f)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  # wide pre-activations: exercises both GELU tails (x - x/(e^2u + 1) with e -> 0 and e -> inf)
+  wi0 = (4.0 * rng.standard_normal((k, f)) / np.sqrt(k)).astype(np.float32)
+  wi1 = (rng.standard_normal((k, f)) / np.sqrt(k)).astype(np.float32)
+  out = torch.empty((m, f), dtype=torch.float32, device='cuda')
+  native.op_geglu(_dev(torch, a), _dev(torch, wi0), _dev(torch, wi1), out)
+  a64 = a.astype(np.float64)
+  ref = ops.gelu_tanh(xp, a64 @ wi0.astype(np.float64)) * (a64 @ wi1.astype(np.float64))
+  err = _relmax(out.cpu().numpy(), ref)
+  print('geglu [%d,%d,%d]: %.2e' % (m, k, f, err))
+  assert err < 3e-5
+  # column identity: a distinct wi_1 column per output catches any mix-up of the 16-column interleave
+  wi1b = np.zeros((k, f), np.float32)
+  wi1b[0, :] = np.arange(1, f + 1)
+  a1 = np.zeros((m, k), np.float32)
+  a1[:, 0] = 1.0
+  wi0b = np.zeros((k, f), np.float32)
+  wi0b[0, :] = 30.0   # gelu(30) == 30 in float32
+  native.op_geglu(_dev(torch, a1), _dev(torch, wi0b), _dev(torch, wi1b), out)
+  np.testing.assert_allclose(out.cpu().numpy()[0], 30.0 * np.arange(1, f + 1), rtol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------------
+# fused QKV with the V^T permutation
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('m,k,j,seg', [(128, 128, 128, 64), (512, 768, 768, 256), (256, 512, 384, 128)])
+def test_qkv_layouts_vs_matmul(env, m, k, j, seg):
+  torch, native = env
+  rng = np.random.default_rng(m + k + j)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  ws = [(rng.standard_normal((k, j)) / np.sqrt(k)).astype(np.float32) for _ in range(3)]
+  outs = [torch.empty((m, j), dtype=torch.float32, device='cuda') for _ in range(3)]
+  native.op_qkv(_dev(torch, a), *[_dev(torch, w) for w in ws], *outs, seg)
+  for name, w, o in zip('qkv', ws, outs):
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    err = _relmax(o.cpu().numpy(), ref)
+    print('qkv %s [%d,%d,%d] seg %d: %.2e' % (name, m, k, j, seg, err))
+    assert err < 2e-5, name
+  # exact probe of the key permutation: V = row index (exact in bf16 hi+lo), identity-like weights
+  a2 = np.zeros((m, k), np.float32)
+  a2[:, 0] = np.arange(m)
+  wv = np.zeros((k, j), np.float32)
+  wv[0, :] = 1.0
+  native.op_qkv(_dev(torch, a2), _dev(torch, ws[0]), _dev(torch, ws[1]), _dev(torch, wv), *outs, seg)
+  np.testing.assert_array_equal(outs[2].cpu().numpy(), np.repeat(np.arange(m, dtype=np.float32)[:, None], j, 1))
+
+
+# --------------------------------------------------------------------------------------------------
+# final projection (exact fp32, decoder_norm folded)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('m,d,n', [(64, 128, 128), (512, 768, 128), (512, 512, 128)])
+def test_final_proj_vs_oracle(env, m, d, n):
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(m + d + n)
+  x = (5.0 * rng.standard_normal((m, d))).astype(np.float32)
+  gamma = (1.0 + 0.3 * rng.standard_normal(d)).astype(np.float32)
+  w = (rng.standard_normal((d, n)) / np.sqrt(d)).astype(np.float32)
+  out = torch.empty((m, n), dtype=torch.float32, device='cuda')
+  native.op_final_proj(_dev(torch, x), _dev(torch, gamma), _dev(torch, w), out)
+  refs = {}
+  for dt in ('float64', 'float32'):
+    xp = backend.NumpyBackend(dt)
+    refs[dt] = np.asarray(xp.matmul(ops.rms_layer_norm(xp, xp.asarray(x), xp.asarray(gamma)), xp.asarray(w)),
+                          np.float64)
+  e_dev, e_f32 = _relmax(out.cpu().numpy(), refs['float64']), _relmax(refs['float32'], refs['float64'])
+  print('final_proj [%d,%d,%d]: device %.2e, float32 oracle %.2e' % (m, d, n, e_dev, e_f32))
+  assert e_dev <= 2e-6 + 2 * e_f32   # plain fp32 arithmetic: same class as the float32 oracle

@@ -117,8 +117,12 @@ def test_predict_seed_uses_documented_philox(tiny_ctx):
   got, _ = model.predict(batch, seed=42, segment=3)
   init_z, noise = philox.segment_noise((1, 64, 128), 6, seed=42, segment=3)
   again, _ = model.predict(batch, init_z=init_z, noise=noise)
-  # same bits in, ulp-level differences only from device vs NumPy log/sin/cos
-  assert helpers.rms(got, again) < 5e-2
+  # same Philox bits in; the draws differ by transcendental ulps (device vs NumPy log/sin/cos, 1e-6
+  # level: tests/test_gpu_ops.py pins that), which a 6-step chain amplifies on the few clip-marginal
+  # elements only: the bulk must agree to 1e-5 and fewer than 0.1 % of the elements may move by > 1e-2
+  e = np.abs(got.astype(np.float64) - again).ravel()
+  print('philox seed vs explicit draws: median %.2e, >1e-2: %.5f, rms %.2e' % (np.median(e), (e > 1e-2).mean(), helpers.rms(got, again)))
+  assert np.median(e) < 1e-5 and (e > 1e-2).mean() < 1e-3
   same, _ = model.predict(batch, seed=42, segment=3)
   np.testing.assert_array_equal(got, same)                       # deterministic
   other, _ = model.predict(batch, seed=43, segment=3)
@@ -190,9 +194,7 @@ def test_predict_sequence_matches_oracle_song(tiny_ctx):
     xp = backend.TorchBackend(dt)
     outs[dt] = predict.predict_song(xp, cfg, dc, params, segs, zs, ns, context_length=64)
   # (device Philox vs NumPy Philox differ by transcendental ulps; chained through 3 segments)
-  e = np.abs(got.astype(np.float64) - outs['float64']).ravel()
-  print('song: median |err| %.2e, outliers(>1e-1) %.4f' % (np.median(e), (e > 1e-1).mean()))
-  assert np.median(e) < 1e-3 and (e > 1e-1).mean() < 0.02
+  helpers.assert_fp32_class(got, outs['float64'], outs['float32'], 'song (3 chained segments)')
   masked = model.predict_sequence(segs, seed=5, always_mask_context=True)
   np.testing.assert_array_equal(masked[:, :64], got[:, :64])   # segment 0 identical
   assert helpers.rms(masked[:, 64:], got[:, 64:]) > 1e-3        # context matters afterwards

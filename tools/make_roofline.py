@@ -1,0 +1,122 @@
+"""profiles/<tag>_{bench_kernel_stats,pmc_fetch,pmc_write,pmc_sq}.csv -> profiles/roofline.json
+
+One entry per kernel class of the DDPM step (the names msd_profile_steps / bench.py use), all per launch:
+  avg_us                    rocprofv3 --kernel-trace --stats average duration (the graph-replayed kernels)
+  algorithmic_gflop, frac   2MNK (or 4 H T S d) / avg_us against the dense bf16 MFMA peak (2.5 PFLOP/s)
+  mfma_util                 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x avg_us x clock): the fraction of SIMD
+                            cycles the MFMA pipe was busy (bf16x3 issues 3 MFMAs per algorithmic product)
+  fabric_bytes_per_launch   2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; FETCH_SIZE doubled: gfx950 counts 16 B/lane
+                            reads at half size, MI355X_MICROARCH.md "HBM"); includes Infinity-Cache hits
+  fabric_gbs                the same / avg_us
+  algorithmic_bytes, waste  every operand read once + every result written once; waste = fabric / algorithmic
+and the sha256 of the library the passes ran on (profiles/<tag>_library_sha.txt, written on the GPU box by
+tools/profile_round.sh) so that bench.py can tell a stale profile from a current one.
+
+Usage: python tools/make_roofline.py <tag> [s_valid]     (s_valid: mean cross-attention keys of the run)"""
+import csv
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+_spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(bench)
+import msd_amd  # noqa: E402
+
+CLOCK_GHZ = 2.4      # MI355X peak engine clock (MI355X_MICROARCH.md); SQ cycle counters tick at the engine clock
+SIMDS = 256 * 4
+# (substring of the demangled kernel name, class) -- first match wins
+CLASS = [
+    ('EpiGeglu', 'gemm_mlp_in_geglu'), ('EpiQKV', 'gemm_qkv'),
+    ('64, 32, 4, msd::EpiResidualNorm', 'gemm_mlp_out'), ('64, 32, 4, EpiResidualNorm', 'gemm_mlp_out'),
+    ('32, 32, 4, msd::EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'), ('32, 32, 4, EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'),
+    ('32, 32, 4, msd::EpiStoreBf16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreBf16', 'gemm_cross_q'),
+    ('attention_merge_kernel', 'attn_cross_merge'),
+    ('attention_kernel<2, 2, 1>', 'attn_self'), ('attention_kernel<2, 2, 2>', 'attn_cross'),
+    ('final_proj_f32_kernel', 'final_proj_f32'), ('EpiInProj', 'in_proj_f32'), ('sampler_step_kernel', 'sampler_step'),
+]
+
+
+def classify(name):
+  for sub, cls in CLASS:
+    if sub in name:
+      return cls
+  return None
+
+
+def main():
+  tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+  s_valid = float(sys.argv[2]) if len(sys.argv) > 2 else 1100.0 + 256.0
+  prof = os.path.join(ROOT, 'profiles')
+  spec = msd_amd.config.preset('base_with_context')
+  flops = bench.class_flops(spec, s_valid, 2)
+  abytes = bench.class_bytes(spec, s_valid, 2)
+  # the shared 32x32 residual template serves two classes with different M: weight by launch share (1:1)
+  flops['gemm_attn_out+gemm_cross_out'] = 0.5 * (flops['gemm_attn_out'] + flops['gemm_cross_out'])
+  abytes['gemm_attn_out+gemm_cross_out'] = 0.5 * (abytes['gemm_attn_out'] + abytes['gemm_cross_out'])
+  flops.setdefault('attn_cross_merge', 0.0)
+  flops.setdefault('sampler_step', 0.0)
+  out = {}
+  with open(os.path.join(prof, '%s_bench_kernel_stats.csv' % tag)) as f:
+    for r in csv.DictReader(f):
+      cls = classify(r['Name'])
+      if cls and cls not in out:
+        out[cls] = {'kernel': r['Name'].split('(')[0].replace('void msd::', '').replace('msd::', ''),
+                    'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 3)}
+
+  def pmc(name):
+    path = os.path.join(prof, '%s_pmc_%s.csv' % (tag, name))
+    if not os.path.exists(path):
+      return {}
+    with open(path) as f:
+      return {classify(r['kernel']): r for r in csv.DictReader(f) if classify(r['kernel'])}
+  fetch, write, sq = pmc('fetch'), pmc('write'), pmc('sq')
+  for cls, e in out.items():
+    us = e['avg_us']
+    e['algorithmic_gflop'] = round(flops.get(cls, 0.0) / 1e9, 4)
+    e['tflops'] = round(flops.get(cls, 0.0) / (us * 1e-6) / 1e12, 2)
+    e['frac'] = round(e['tflops'] / bench.PEAK_BF16_TFLOPS, 5)
+    if cls in sq and 'SQ_VALU_MFMA_BUSY_CYCLES' in sq[cls]:
+      busy = float(sq[cls]['SQ_VALU_MFMA_BUSY_CYCLES'])
+      e['mfma_busy_cycles'] = busy
+      e['mfma_util'] = round(busy / (SIMDS * us * 1e-6 * CLOCK_GHZ * 1e9), 4)
+    if cls in fetch:
+      fb = (2.0 * float(fetch[cls]['FETCH_SIZE']) + float(write.get(cls, {}).get('WRITE_SIZE', 0.0))) * 1024
+      e['fabric_bytes_per_launch'] = int(round(fb))
+      e['fabric_gbs'] = round(fb / (us * 1e-6) / 1e9, 1)
+      ab = abytes.get(cls)
+      if ab:
+        e['algorithmic_bytes'] = int(ab)
+        e['waste'] = round(fb / ab, 2)
+  sha_path = os.path.join(prof, '%s_library_sha.txt' % tag)
+  sha = open(sha_path).read().strip() if os.path.exists(sha_path) else 'unknown (%s predates the stamp)' % tag
+  launches = {'gemm_attn_out+gemm_cross_out': 24, 'final_proj_f32': 1, 'in_proj_f32': 1, 'sampler_step': 1}
+  step_us = sum(e['avg_us'] * launches.get(c, 12) for c, e in out.items())
+  step_fabric = sum(e.get('fabric_bytes_per_launch', 0) * launches.get(c, 12) for c, e in out.items())
+  step_alg = sum(e.get('algorithmic_bytes', 0) * launches.get(c, 12) for c, e in out.items())
+  doc = {
+      'tag': tag, 'library_sha': sha,
+      'source': 'rocprofv3 --kernel-trace --stats and separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group) over '
+                'bench.py, base_with_context B=1 bf16x3 CFG (tools/profile_round.sh %s); profiles/%s_*.csv' % (tag, tag),
+      'assumptions': {'clock_ghz': CLOCK_GHZ, 'simds': SIMDS, 'peak_bf16_tflops': bench.PEAK_BF16_TFLOPS,
+                      's_valid_keys': s_valid,
+                      'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 16 B/lane reads at half size); WRITE_SIZE as reported'},
+      'whole_step': {'sum_kernel_us': round(step_us, 1), 'fabric_bytes': int(step_fabric), 'algorithmic_bytes': int(step_alg),
+                     'waste': round(step_fabric / step_alg, 2) if step_alg else None,
+                     'fabric_gbs': round(step_fabric / (step_us * 1e-6) / 1e9, 1) if step_us else None},
+      'per_class': out,
+  }
+  with open(os.path.join(prof, 'roofline.json'), 'w') as f:
+    json.dump(doc, f, indent=1)
+  for c, e in sorted(out.items(), key=lambda kv: -kv[1]['avg_us']):
+    print('%-30s %7.2f us  %7.1f TF  frac %.4f  mfma %s  fabric %s MB (%s GB/s)  waste %s' % (
+        c, e['avg_us'], e['tflops'], e['frac'], e.get('mfma_util'), round(e.get('fabric_bytes_per_launch', 0) / 1e6, 1),
+        e.get('fabric_gbs'), e.get('waste')))
+  print('step: %.1f us kernels, fabric %.2f GB vs algorithmic %.2f GB' % (step_us, step_fabric / 1e9, step_alg / 1e9))
+
+
+if __name__ == '__main__':
+  main()

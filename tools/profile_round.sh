@@ -1,0 +1,29 @@
+#!/bin/bash
+# One profiling round on the GPU box: kernel-trace stats of a full bench step + separate PMC passes, all
+# stamped with the hash of the library they ran on.  Outputs -> gpurun_out/<tag>_*; copy to profiles/ and run
+# `python tools/make_roofline.py <tag>` afterwards (here, in the container).
+# usage: bash tools/profile_round.sh <tag>
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+sha256sum $ROOT/music-spectrogram-diffusion_amd/csrc/libmsd_amd.so | cut -c1-16 > $OUT/${TAG}_library_sha.txt
+# 1. kernel trace + stats over one full 1000-step segment (+1 warm-up): what the graph replays
+rm -rf /tmp/prof_$TAG
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- \
+    python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --batched-songs 0 --profile-steps 1 > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof_$TAG.err
+find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
+# 2. PMC passes (one counter group per pass, kernel-trace only), 100 DDPM steps so that the encoder's launches
+#    of the same templates are < 3 % of the dispatches
+run_pass() {  # name, counters
+  rm -rf /tmp/pmc_$1
+  timeout 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d /tmp/pmc_$1 -- \
+      python $ROOT/bench.py --steps 1 --warmup 0 --num-steps 100 --no-cpu-baseline --batched-songs 0 --profile-steps 1 > /tmp/pmc_$1.log 2>&1
+  f=$(find /tmp/pmc_$1 -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then python $ROOT/tools/pmc_summary.py $f > $OUT/${TAG}_pmc_$1.csv; else echo "no counters for $1"; tail -5 /tmp/pmc_$1.log; fi
+}
+run_pass fetch "FETCH_SIZE"
+run_pass write "WRITE_SIZE"
+run_pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+ls -la $OUT/${TAG}_*

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "gemm_bf16_regstaged.h"
 using namespace msd;
 
 template <int NP, int BM, int BN, int R, bool DMA = false>
