@@ -168,6 +168,10 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id,
                const float* init_z_dev, const float* noise_dev, float* out_dev,
                void* stream);
 
+/* Drop the captured hipGraph of the DDPM step; the next msd_sample captures it again (launch-time
+ * tunables such as the MSD_XCD_* environment switches are read during capture: tools/sweep_xcd.py). */
+int msd_reset_graph(msd_model* m);
+
 /* One decoder call of the scan body: pred_fn(z, time=(i+1)/N, include_conditioning)
  * (models.py:373-386 -> network.py:561-573).  For parity tests and profiling.
  *   z_dev float [batch,T,n]; eps_out_dev float [batch,T,n]                     */

@@ -1349,6 +1349,14 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   return MSD_OK;
 }
 
+int msd_reset_graph(msd_model* m) {
+  if (!m) return MSD_ERR_INVALID_ARGUMENT;
+  if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+  if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
+  m->graph_batch = 0;
+  return MSD_OK;
+}
+
 int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev,
                      int include_conditioning, float* eps_out_dev, void* stream) {
   if (!m) return MSD_ERR_INVALID_ARGUMENT;

@@ -33,7 +33,7 @@ PRECISIONS = {'bf16': MSD_PREC_BF16, 'bf16x3': MSD_PREC_BF16X3}
 EXPORTED_SYMBOLS = (
     'msd_version', 'msd_device_count', 'msd_create', 'msd_destroy', 'msd_last_error',
     'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
-    'msd_encode', 'msd_sample', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
+    'msd_encode', 'msd_sample', 'msd_reset_graph', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
     'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
     'msd_op_attention', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
     'msd_op_qkv', 'msd_op_final_proj')
@@ -102,6 +102,7 @@ def load() -> ctypes.CDLL:
   lib.msd_encode.argtypes = [vp, i32, vp, vp, vp, vp]
   lib.msd_sample.argtypes = [vp, i32, u64, u64, vp, vp, vp, vp]
   lib.msd_decoder_pass.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+  lib.msd_reset_graph.argtypes = [vp]
   lib.msd_fill_normal.argtypes = [u64, u64, u32, vp, i64, vp]
   lib.msd_get_schedule.argtypes = [vp, vp]
   lib.msd_debug_read.argtypes = [vp, c.c_char_p, vp, i64, c.POINTER(i64)]
@@ -217,6 +218,9 @@ class NativeModel:
     _check(self.lib, self.handle,
            self.lib.msd_sample(self.handle, batch, seed, stream_id, _ptr(init_z), _ptr(noise),
                                _ptr(out), stream), 'msd_sample')
+
+  def reset_graph(self):
+    _check(self.lib, self.handle, self.lib.msd_reset_graph(self.handle), 'msd_reset_graph')
 
   def decoder_pass(self, batch: int, step_index: int, z, include_conditioning: bool, eps_out,
                    stream: int = 0):

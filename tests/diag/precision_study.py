@@ -35,8 +35,50 @@ MM_VARIANTS = {
 }
 
 
+# 8-bit lo planes: the lo plane of the GEMM operands stored as fp8 with one power-of-two
+# scale per row of K (what a 16+8-bit operand with v_cvt_scalef32_pk_bf16_fp8 on the way to the MFMA would
+# hold): cuts the L2 -> LDS bytes of that operand by 25 %.  'a' = activations, 'w' = weights.
+LO8_VARIANTS = {
+    'lo8_a_e4m3': ('a', 'e4m3'), 'lo8_w_e4m3': ('w', 'e4m3'), 'lo8_aw_e4m3': ('aw', 'e4m3'),
+    'lo8_a_e5m2': ('a', 'e5m2'), 'lo8_w_e5m2': ('w', 'e5m2'),
+}
+
+
+def _fp8_round(xp, lo, kind):
+  """lo -> fp8 (per-row power-of-two scale so that the row maximum lands in the top binade) -> back."""
+  import torch
+  t = lo if isinstance(lo, torch.Tensor) else torch.as_tensor(np.asarray(lo))
+  dt = torch.float8_e4m3fn if kind == 'e4m3' else torch.float8_e5m2
+  top = 448.0 if kind == 'e4m3' else 57344.0
+  amax = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+  scale = torch.exp2(torch.ceil(torch.log2(amax / top)))
+  q = (t / scale).to(dt).to(t.dtype) * scale
+  return q
+
+
 class StudyModel(fast.FastModel):
   variant = 'x3'
+
+  def _split(self, a, which='a'):
+    parts = super()._split(a)
+    if self.variant in LO8_VARIANTS and len(parts) == 2:
+      who, kind = LO8_VARIANTS[self.variant]
+      if which in who:
+        lo = _fp8_round(self.xp, a - parts[0], kind)   # quantise the exact residual, not its bf16 rounding
+        return (parts[0], lo)
+    return parts
+
+  def _w(self, name):
+    if name not in self._wcache:
+      # weights [K, N]: the device stores W^T rows of K, so the scale runs along K = axis 0 here
+      w = self.p[name]
+      if self.variant in LO8_VARIANTS and 'w' in LO8_VARIANTS[self.variant][0]:
+        hi = self.xp.round_bf16(w)
+        lo = _fp8_round(self.xp, (w - hi).T, LO8_VARIANTS[self.variant][1]).T
+        self._wcache[name] = (hi, lo)
+      else:
+        self._wcache[name] = fast.FastModel._split(self, w)
+    return self._wcache[name]
 
   def _mm_parts(self, a_parts, w_parts):
     if self.variant not in MM_VARIANTS:
@@ -109,4 +151,4 @@ def main(names):
 
 
 if __name__ == '__main__':
-  main(sys.argv[1:] or list(VARIANTS) + list(MM_VARIANTS))
+  main(sys.argv[1:] or list(VARIANTS) + list(MM_VARIANTS) + list(LO8_VARIANTS))

@@ -57,7 +57,13 @@ def song(preset, n_segments, name, weight_seed=0, seed=0, dtype='float64', threa
   c = spec.task_feature_lengths.get('targets_context')
   pred = np.zeros((1, c or 0, n), np.float32)
   outs = []
-  for k in range(n_segments):
+  path = os.path.join(HERE, name)
+  if os.environ.get('CHAIN_RESUME') and os.path.exists(path):   # continue an interrupted chain
+    done = np.load(path)
+    outs = [done['mel'][:, k * t:(k + 1) * t] for k in range(int(done['n_segments']))]
+    pred = outs[-1]
+    print('%s: resuming after segment %d' % (name, len(outs) - 1), flush=True)
+  for k in range(len(outs), n_segments):
     t0 = time.time()
     batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, k)}
     if spec.has_context:

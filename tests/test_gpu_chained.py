@@ -71,11 +71,23 @@ def test_two_ranks_one_song_bit_identical_to_sequential(preset, steps, n_seg):
   procs = [ctx.Process(target=_worker, args=(r, 2, port, preset, steps, n_seg, q)) for r in range(2)]
   for p in procs:
     p.start()
+  import queue
+  import time
+  result, deadline = None, time.time() + 600
   try:
-    full, seq, wave_full, wseq = q.get(timeout=900)
+    while result is None:
+      try:
+        result = q.get(timeout=2)
+      except queue.Empty:
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        assert not dead, 'a rank died with exit code %s before delivering its result' % dead
+        assert time.time() < deadline, 'ranks did not finish in 600 s'
   finally:
     for p in procs:
-      p.join(timeout=120)
+      p.join(timeout=60)
+      if p.is_alive():
+        p.kill()
+  full, seq, wave_full, wseq = result
   assert all(p.exitcode == 0 for p in procs)
   assert full.shape == seq.shape and np.isfinite(seq).all() and seq.std() > 0.1
   np.testing.assert_array_equal(full, seq)       # bit-for-bit: same kernels, same inputs, same noise keys
@@ -101,7 +113,7 @@ def test_device_resident_handoff_between_two_handles():
   np.testing.assert_array_equal(got, seq)
   # and the masked-boundary mode differs exactly from the cut on (the reference's i == 0 behaviour there)
   from msd_amd import sharding
-  parts = [sharding.masked_boundary_predict(a.predict_sequence, segs, r, 2) for r in range(2)]
+  parts = [sharding.masked_boundary_predict(a.predict_sequence, segs, r, 2, seed=1) for r in range(2)]
   cut = sharding.contiguous_chunk(len(segs), 1, 2)[0] * spec.task_feature_lengths['targets']
   masked = np.concatenate(parts, 1)
   np.testing.assert_array_equal(masked[:, :cut], seq[:, :cut])

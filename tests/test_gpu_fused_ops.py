@@ -125,6 +125,8 @@ def test_schedule_table_linear_and_cosine_vs_oracle(env):
   torch, native = env
   import msd_amd
   from oracle import backend, sampler
+  # the device evaluates the schedule in float32 like the reference (jnp): near t = 1 the cosine
+  # schedule sits on the pole of tan (logsnr = -20), where float32 is ~5e-5 relative from float64
   xp = backend.NumpyBackend('float64')
   for case in (dict(), dict(schedule='linear', train='linear')):
     spec = _sampler_spec(steps=40, **case)
@@ -137,9 +139,9 @@ def test_schedule_table_linear_and_cosine_vs_oracle(env):
     ss = sampler.DiffusionSchedule(d.sampler.schedule.name, d.sampler.schedule.start, d.sampler.schedule.stop, n)
     ts = sampler.DiffusionSchedule(d.train_schedule.name, d.train_schedule.start, d.train_schedule.stop,
                                    d.train_schedule.num_steps)
-    np.testing.assert_allclose(tab[:, 0], sampler.get_logsnr_t(xp, t, ss), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(tab[:, 1], sampler.get_logsnr_t(xp, s, ss), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(tab[:, 7], sampler.get_logsnr_t(xp, t, ts), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tab[:, 0], sampler.get_logsnr_t(xp, t, ss), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(tab[:, 1], sampler.get_logsnr_t(xp, s, ss), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(tab[:, 7], sampler.get_logsnr_t(xp, t, ts), rtol=1e-4, atol=2e-5)
 
 
 # --------------------------------------------------------------------------------------------------
