@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libmsd_amd.so')
 SOURCES = ['msd_api.hip']
-HEADERS = ['common.h', 'gemm_bf16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
+HEADERS = ['common.h', 'chain.h', 'gemm_bf16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
            os.path.join('..', '..', 'include', 'msd_amd.h')]
 
 

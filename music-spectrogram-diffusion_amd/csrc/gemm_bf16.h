@@ -77,8 +77,12 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // row-major; the XOR swizzle that makes ds_read_b128 conflict-free is therefore
 // applied to the per-lane SOURCE address (lane (r, c') fetches global chunk c' ^ r).
 // ----------------------------------------------------------------------------
-template <int NP, int BM, int BN, int NS, class Epi>
-__global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi epi) {
+// One output tile (bm, bn) by the 256 threads of the calling block; `smem` = the block's dynamic LDS
+// (gemm_bf16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
+// kernel may have produced (A planes, residual tile, row statistics): 0 in the stand-alone kernel, 16 (sc1:
+// bypass the CU's L1, served by the XCD's L2) inside the XCD-resident chain kernels (chain.h).
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -87,29 +91,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   constexpr int PW = NP * (A_LD + B_LD);          // DMA instructions per wave per K-tile
   constexpr int LDS_LD = BN + kSlabPad;
   static_assert((BM * LDS_LD + BM) * 4 <= NS * STAGE_BYTES, "epilogue slab must fit the operand LDS");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
-  // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
-  // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
-  // With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
-  // bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
-  // traffic when the activations are as large as the weights (N = D projections).
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  const int RX = p.xcd_rows, CX = 8 / RX;
-  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
-  const int nbm_x = (nbm + RX - 1) / RX, nbn_x = (nbn + CX - 1) / CX;
-  int bm, bn;
-  if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
-    bm = (tt / nbn_x) * RX + xcd / CX; bn = (tt % nbn_x) * CX + xcd % CX;
-  } else {              // row tiles fastest (a weight slice stays hot)
-    bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
-  }
-  if (bn >= nbn || bm >= nbm) return;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
@@ -133,7 +118,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                     \
       _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                      \
           __builtin_amdgcn_global_load_lds((gptr_t)(ga[pl] + i * a_step + k0_),             \
-              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, 0);  \
+              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, CP); \
       _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                      \
           __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl] + i * b_step + k0_),             \
               (lptr_t)(base_ + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * i) * 128), 16, 0, 0); \
@@ -157,7 +142,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
   // over-wait by these few instructions) and the final vmcnt(0) covers them.
   char* const aux = smem + NS * STAGE_BYTES;
-  epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
+  epi.template prefetch<BM, BN, CP>(aux, m0, n0, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
 
   // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF (prologue only; the
@@ -212,7 +197,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     const int k0_ = (KT) * kGemmBK;                                                          \
     if (r_ < A_LD)                                                                           \
       __builtin_amdgcn_global_load_lds((gptr_t)(ga[pl_] + r_ * a_step + k0_),                \
-          (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, 0);     \
+          (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, CP);    \
     else                                                                                     \
       __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl_] + (r_ - A_LD) * b_step + k0_),       \
           (lptr_t)(base_ + NP * A_BYTES + pl_ * B_BYTES + (wave * (BN / 4) + 8 * (r_ - A_LD)) * 128), 16, 0, 0); \
@@ -328,6 +313,29 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
   epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true);
 }
 
+template <int NP, int BM, int BN, int NS, class Epi>
+__global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
+  // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
+  // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
+  // With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
+  // bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
+  // traffic when the activations are as large as the weights (N = D projections).
+  const int nbm = p.M / BM, nbn = p.N / BN;
+  const int RX = p.xcd_rows, CX = 8 / RX;
+  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
+  const int nbm_x = (nbm + RX - 1) / RX, nbn_x = (nbn + CX - 1) / CX;
+  int bm, bn;
+  if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
+    bm = (tt / nbn_x) * RX + xcd / CX; bn = (tt % nbn_x) * CX + xcd % CX;
+  } else {              // row tiles fastest (a weight slice stays hot)
+    bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
+  }
+  if (bn >= nbn || bm >= nbm) return;
+  gemm_tile<NP, BM, BN, NS, Epi, 0>(p, epi, bm, bn, smem);
+}
+
 // ----------------------------------------------------------------------------
 // Epilogues.  run<BM,BN,LD>(slab, m0, n0, tid): tile value (m,n) = slab[m*LD+n].
 // ----------------------------------------------------------------------------
@@ -387,12 +395,13 @@ typedef __attribute__((address_space(3))) void* aux_lptr_t;
 // LDS-DMA of `bytes` contiguous, 16-byte aligned global bytes to dst (linear), one 1 KiB
 // instruction per wave round-robin.  Lanes past the end re-fetch the last chunk; their LDS
 // writes land in the padding (dst needs round_up(bytes, 1024) bytes).
+template <int CP = 0>
 __device__ __forceinline__ void aux_dma_linear(const void* g, char* dst, int bytes, int wave, int lane) {
   const int n_instr = (bytes + 1023) >> 10;
   for (int i = wave; i < n_instr; i += 4) {
     int off = i * 1024 + lane * 16;
     off = off < bytes - 16 ? off : bytes - 16;
-    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)(dst + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)(dst + i * 1024), 16, 0, CP);
   }
 }
 
@@ -407,10 +416,10 @@ __device__ __forceinline__ void aux_dma_row(const void* g, char* dst, int bytes,
 template <int BM>
 constexpr int rowscale_aux_bytes() { return BM * kAuxMaxTiles * 4 + 1024; }
 
-template <int BM, int BN>
+template <int BM, int BN, int CP = 0>
 __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, int m0, int n0, int wave, int lane) {
   if (!r.ssq) return;
-  aux_dma_linear(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
+  aux_dma_linear<CP>(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
   if (r.bias && wave == 3)
     aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + BM * kAuxMaxTiles * 4, BN * 4, lane);
 }
@@ -471,9 +480,9 @@ struct EpiStoreBf16 {
   int ldc;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -507,9 +516,9 @@ struct EpiQKV {
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -572,7 +581,7 @@ struct EpiResidual {
   float* x;
   int ldx;
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
@@ -610,14 +619,14 @@ struct EpiResidualNorm {
   template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 + 2048 : 0; }
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     if (BN != 32) return;
     // rows of 128 B: lane (r = lane>>3, c = lane&7) fetches 16 B of row 8i + r
     for (int i = wave; i < BM / 8; i += 4)
       __builtin_amdgcn_global_load_lds(
           (aux_gptr_t)(x + (size_t)(m0 + 8 * i + (lane >> 3)) * ldx + n0 + (lane & 7) * 4),
-          (aux_lptr_t)(aux + i * 1024), 16, 0, 0);
+          (aux_lptr_t)(aux + i * 1024), 16, 0, CP);
     const int step = *step_ptr;
     if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)step * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
@@ -698,7 +707,7 @@ struct EpiInProj {
   const int* step_ptr;
   int* step_copy = nullptr;   // = step_ptr when the sampler follows in the same step
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
@@ -747,9 +756,9 @@ struct EpiStoreF32 {
   int ldc;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -785,9 +794,9 @@ struct EpiGeglu {
   int ldc;  // = F
   RowScale rsc;  // bias table is indexed by PACKED column
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {

@@ -16,6 +16,7 @@
 
 #include "../../include/msd_amd.h"
 #include "attention.h"
+#include "chain.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_bf16.h"
@@ -29,11 +30,11 @@ constexpr int kHeadDim = 64;
 
 enum KClass { KC_NORM = 0, KC_GEMM_QKV, KC_ATTN_SELF, KC_GEMM_ATTN_OUT, KC_GEMM_CROSS_Q,
               KC_ATTN_CROSS, KC_GEMM_CROSS_OUT, KC_GEMM_MLP_IN, KC_GEMM_MLP_OUT,
-              KC_FINAL_PROJ, KC_SAMPLER, KC_IN_PROJ, KC_COUNT };
+              KC_FINAL_PROJ, KC_SAMPLER, KC_IN_PROJ, KC_CHAIN_MLP, KC_COUNT };
 const char* const kClassNames[KC_COUNT + 1] = {
     "rmsnorm_film", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
     "gemm_cross_out", "gemm_mlp_in_geglu", "gemm_mlp_out", "final_proj_f32", "sampler_step",
-    "in_proj_f32", nullptr};
+    "in_proj_f32", "chain_mlp_qkv", nullptr};
 
 struct Planes {
   bf16_t* p[2] = {nullptr, nullptr};
@@ -149,6 +150,11 @@ struct msd_model {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
+  // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
+  bool chain_mlp = false;
+  int cus = 0;                 // compute units of the device (chain grid = one block per CU)
+  unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
+  int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
   Profiler prof;
 };
@@ -875,17 +881,25 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     return r;
   };
   auto g_tab = [&](int slot) { return m->d_g + (size_t)slot * D; };  // + step * slots * D in the kernel
-  for (int l = 0; l < m->Ld; ++l) {
-    const DecLayerW& w = m->dec[l];
-    // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
-    // through one norm kernel; later layers consume the folded-norm planes `y` written by the
-    // previous layer's MLP output projection.
+  // fused q|k|v projection of layer l (network.py:181-189 via layers.py:262-264) on the folded-norm planes y
+  auto qkv_epi = [&](int l) {
     EpiQKV<NP> eq;
     eq.qk[0] = qk.p[0]; eq.qk[1] = qk.p[NP - 1];
     eq.vt[0] = vts.p[0]; eq.vt[1] = vts.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
     eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
-    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
+    return eq;
+  };
+  const bool chain = m->chain_mlp && NP == 2 && M % 64 == 0 && M < big_m_threshold();
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW& w = m->dec[l];
+    // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
+    // through one norm kernel; later layers consume the folded-norm planes `y` written by the
+    // previous layer's MLP output projection (inside that layer's chain launch when chains are on).
+    if (!chain || l == 0) {
+      const EpiQKV<NP> eq = qkv_epi(l);
+      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
+    }
     const bf16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                   (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch);
@@ -920,12 +934,29 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     EpiGeglu<NP> eg;
     eg.out[0] = gb.p[0]; eg.out[1] = gb.p[NP - 1]; eg.ldc = F;
     eg.rsc = rowscale(m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F);
-    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg);
     EpiResidualNorm<NP> eo = er;
     const bool last = (l + 1 == m->Ld);
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
+    if constexpr (NP == 2) {
+      if (chain) {   // MLP-in -> MLP-out -> QKV of layer l+1: one XCD-resident launch (chain.h)
+        MlpChainParams<NP> cp;
+        cp.g_in = gp<NP>(y, D, w.mlp.wi, D, M, 2 * F, D);     cp.e_in = eg;
+        cp.g_out = gp<NP>(gb, F, w.mlp.wo, F, M, D, F);       cp.e_out = eo;
+        cp.has_qkv = last ? 0 : 1;
+        cp.g_qkv = gp<NP>(y, D, m->dec[last ? l : l + 1].self.wqkv, D, M, 3 * J, D);
+        cp.e_qkv = qkv_epi(last ? l : l + 1);
+        cp.bar = m->d_bar; cp.err = m->d_chain_err;
+        c.begin(KC_CHAIN_MLP);
+        const hipError_t e = ((3 * J) % 96 == 0 && (2 * J) % 96 == 0) ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s)
+                                                                       : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
+        if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+        c.end(KC_CHAIN_MLP);
+        continue;
+      }
+    }
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg);
     gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo);
   }
   // decoder_norm + spec_out_dense (network.py:445-456).  The reference keeps this
@@ -1012,6 +1043,8 @@ void set_func_attrs() {
   (void)attention_prepare<2, 2>();
   (void)prepare_gemms<1>();
   (void)prepare_gemms<2>();
+  (void)mlp_chain_prepare<2, 96>();
+  (void)mlp_chain_prepare<2, 64>();
 }
 
 }  // namespace
@@ -1066,6 +1099,21 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      m->cus = cus;
+    // chain.h: needs the block -> XCD round robin over 8 XCDs with equal CU counts, the folded norms, bf16x3 and
+    // tile-aligned widths (64 x 128 gated tiles, 64 x 32 output tiles, 64 x 96 or 64 x 64 QKV tiles)
+    // OFF by default: measured on the MI355X (profiles/r02_chain_ab.log) the chain is 7 % SLOWER per step than
+    // the separate launches -- one row tile per XCD means every XCD streams every weight tile through its own
+    // L2 (the 2 x 4 XCD grid of the stand-alone GEMMs shares each weight tile between 4 row tiles), which costs
+    // what the two saved kernel boundaries win.  MSD_CHAIN=1 turns it on (parity-tested, tests/test_gpu_model.py).
+    const char* v = getenv("MSD_CHAIN");
+    m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && cfg->precision == MSD_PREC_BF16X3 && m->cus >= 8 &&
+                   m->cus % 8 == 0 && (2 * cfg->mlp_dim) % 128 == 0 && cfg->emb_dim % 32 == 0 &&
+                   (3 * cfg->num_heads * kHeadDim) % 64 == 0;
+  }
   // encode_impl writes round_up(Lv, 64) token rows and then round_up(Cv, 64) context rows from row Lv
   m->S_pad = round_up(m->L, 64) + round_up(m->C, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
@@ -1103,6 +1151,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->z, (size_t)m->Bmax * T * m->ND));
   TRY(dalloc(m, &m->d_noise_slot, 1));
   TRY(dalloc(m, &m->d_step, 2));
+  TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
+  TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
   TRY(dalloc(m, &m->d_nkeys_cross, (size_t)m->Bmax));
   m->h_nkeys_cross.assign(m->Bmax, 0);
@@ -1308,6 +1358,11 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
+  if (m->chain_mlp) {   // a timed-out XCD barrier of an earlier call (chain.h) must not go unnoticed
+    int bad = 0;
+    HIP_TRY(m, hipMemcpy(&bad, m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) return fail(m, MSD_ERR_HIP, "an XCD-resident chain kernel timed out at a barrier (%d): set MSD_CHAIN=0", bad);
+  }
 
   // One graph = `graph_steps` consecutive DDPM steps (the scan index lives in device memory, so
   // the same graph serves every position); a second, single-step graph covers N mod graph_steps.

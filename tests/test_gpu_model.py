@@ -348,3 +348,31 @@ def test_key_split_cross_attention_edge_lengths(valid):
       want = fm.decoder_pass(z.astype(np.float64), step, True)
       err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
       assert err < 2e-4, (valid, mask, step, err)
+
+
+def test_xcd_resident_chain_kernel_matches_separate_launches(monkeypatch):
+  """MSD_CHAIN=1: MLP-in -> MLP-out -> next layer's QKV as ONE launch whose phases are separated by
+  XCD-local barriers (csrc/chain.h; off by default because it measured slower).  Same tiles, same arithmetic:
+  the eps of a decoder pass and a whole sampled segment must agree with the separate-launch path."""
+  import torch
+  spec = msd_amd.config.preset('tiny_context', num_steps=6)
+  params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
+  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  outs, eps = {}, {}
+  for chain in ('0', '1'):
+    monkeypatch.setenv('MSD_CHAIN', chain)
+    model = msd_amd.InferenceModel(params, spec, batch_size=2)
+    outs[chain], _ = model.predict(batch, init_z=init_z, noise=noise)
+    nm = model._get_native()
+    z = torch.as_tensor(init_z).cuda()
+    e = torch.zeros_like(z)
+    nm.decoder_pass(2, 3, z, True, e)
+    torch.cuda.synchronize()
+    eps[chain] = e.cpu().numpy()
+  rel = np.abs(eps['1'] - eps['0']).max() / np.abs(eps['0']).max()
+  print('chain vs separate launches: decoder pass max rel diff %.2e' % rel)
+  assert rel < 1e-5
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  helpers.assert_fp32_class(outs['1'], ref64, ref32, 'chain')
