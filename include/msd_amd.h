@@ -86,8 +86,7 @@ typedef enum msd_logvar_kind {
 /* Hyper-parameters: network.T5Config (network.py:54-72), DiffusionConfig & co
  * (diffusion_utils.py:25-59), %TASK_FEATURE_LENGTHS (inference.py:97-101) and the
  * codec range (audio_codecs.py:207-213).  Fixed by construction on this path:
- * decoder_cross_attend_style="concat_encodings", mlp_activations=("gelu","linear"),
- * head_dim=64; anything else is rejected by the Python layer / msd_create. */
+ * mlp_activations=("gelu","linear"), head_dim=64; anything else is rejected by the Python layer / msd_create. */
 typedef struct msd_config {
   int32_t struct_size;            /* sizeof(msd_config), ABI check */
   int32_t has_context;            /* 0 DiffusionModel, 1 ContextDiffusionModel */
@@ -124,6 +123,9 @@ typedef struct msd_config {
   float train_schedule_start;     /* linear only */
   float train_schedule_stop;
   int32_t train_schedule_num_steps;
+  int32_t cross_attend_sum;       /* T5Config.decoder_cross_attend_style: 0 = "concat_encodings" (every shipped
+                                     gin), 1 = "sum_cross_attends" (the dataclass default, network.py:199-216:
+                                     one cross-attention module per encoding, outputs summed) */
 } msd_config;
 
 const char* msd_version(void);

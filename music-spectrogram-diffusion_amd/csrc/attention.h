@@ -43,6 +43,7 @@ struct AttnParams {
   size_t k_seg_stride;  // elements between segments of k
   size_t vt_seg_stride; // elements between segments of vt
   int k_rows;           // allocated key rows per segment (DMA source rows are clamped to it)
+  int vt_cols = 0;      // readable key columns of a V^T row from `vt` (0 = vt_ld); smaller when `vt` points into a row
   // key split across blocks (cross-attention: more CUs for the long key axis).  ksplit > 1:
   // block (q-group, ks) takes stages ks, ks+ksplit, ... and writes its un-normalised partial
   // (O relative to its own max m, and m, l) to the workspace; attention_merge_kernel finishes.
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
     kseg[pl] = p.k[pl] + (size_t)seg * p.k_seg_stride + head * 64 + kc * 8;
     vseg[pl] = p.vt[pl] + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64) * p.vt_ld;
   }
-  const int last_row = p.k_rows - 1, last_kcol = p.vt_ld - 8;
+  const int last_row = p.k_rows - 1, last_kcol = (p.vt_cols > 0 ? p.vt_cols : p.vt_ld) - 8;
 
 #define MSD_A_ISSUE(ST, BUF)                                                                      \
   {                                                                                               \

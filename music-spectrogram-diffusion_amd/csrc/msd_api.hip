@@ -65,9 +65,11 @@ struct EncLayerW {
 struct DecLayerW {
   const float *ln_self = nullptr, *ln_cross = nullptr, *ln_mlp = nullptr;
   AttnW self;
-  Planes wq_cross;   // [J, D]
-  Planes wkv_cross;  // [2J, D] (k|v)
-  Planes wo_cross;   // [D, J]
+  // one cross-attention module per key region: [0] = MultiHeadDotProductAttention_0 (concat_encodings: the
+  // concatenated encodings; sum_cross_attends: the token encoder), [1] = ..._1 (sum_cross_attends: the context)
+  Planes wq_cross[2];   // [J, D]
+  Planes wkv_cross[2];  // [2J, D] (k|v)
+  Planes wo_cross[2];   // [D, J]
   MlpW mlp;
 };
 struct EncoderW {
@@ -123,7 +125,8 @@ struct msd_model {
   Planes w_in_p, w_out_p;      // packed W^T of continuous_inputs_projection [D][n] / spec_out_dense [n][D]
   float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
   float *att_part_o = nullptr, *att_part_ml = nullptr;  // key-split attention partials
-  int cross_ksplit = 1;
+  int cross_ksplit = 1;        // key split of the cross-attention at batch 1 (allocation bound)
+  bool cross_ksplit_fixed = false;   // MSD_CROSS_KSPLIT given: use it at every batch size
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
@@ -132,8 +135,11 @@ struct msd_model {
   const float** d_noise_slot = nullptr;
   int* d_step = nullptr;       // [2]
   int* d_nkeys_self = nullptr; // [passes*Bmax] = T
-  int* d_nkeys_cross = nullptr;// [Bmax]
+  int* d_nkeys_cross = nullptr;// [n_cross][Bmax] valid keys per key region and song
   std::vector<int> h_nkeys_cross;
+  int n_cross = 1;             // cross-attention modules per decoder layer (2: sum_cross_attends with context)
+  int key_off[2] = {0, 0};     // first key row of each region in the cross cache
+  Planes cq2, ao2;             // second module's query / attention output (sum_cross_attends)
   Planes kc, vtc;              // cross cache [Ld][Bmax][S_pad][J] / [Ld][Bmax][J][S_pad]
 
   // encoder scratch (one sequence at a time)
@@ -253,7 +259,7 @@ void declare_weights(msd_model* m) {
     add_weight(m, lp + "/FiLMLayer_0/DenseGeneral_0/kernel", 4 * D, 2 * D);
     attention(lp + "/self_attention");
     add_weight(m, lp + "/pre_cross_attention_layer_norm/scale", D);
-    attention(lp + "/MultiHeadDotProductAttention_0");
+    for (int e = 0; e < m->n_cross; ++e) attention(lp + "/MultiHeadDotProductAttention_" + std::to_string(e));
     add_weight(m, lp + "/pre_mlp_layer_norm/scale", D);
     add_weight(m, lp + "/FiLMLayer_1/DenseGeneral_0/kernel", 4 * D, 2 * D);
     mlp(lp + "/mlp");
@@ -444,7 +450,7 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1) {
+               int segs, int ksplit = 1, int vt_cols = 0) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -452,7 +458,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2
   }
   p.n_keys = n_keys; p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
   p.q_rows_per_seg = q_rows_per_seg; p.k_seg_stride = k_seg_stride;
-  p.vt_seg_stride = vt_seg_stride; p.k_rows = k_rows;
+  p.vt_seg_stride = vt_seg_stride; p.k_rows = k_rows; p.vt_cols = vt_cols;
   p.ksplit = ksplit; p.part_o = c.m->att_part_o; p.part_ml = c.m->att_part_ml;
   p.total_rows = q_rows_per_seg * segs;
   c.begin(kc);
@@ -774,8 +780,11 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
                            m->ex, D);
         encoder_stack<NP>(c, m->ctx_enc, rows, 1);
         Planes enc_ctx;
-        enc_ctx.p[0] = m->enc.p[0] + (size_t)Lv * D;
-        enc_ctx.p[1] = NP == 2 ? m->enc.p[1] + (size_t)Lv * D : nullptr;
+        // concat_encodings: right behind the valid tokens (one compact key axis); sum_cross_attends: its own
+        // key region at a fixed offset
+        const size_t ctx_row = m->n_cross == 2 ? (size_t)m->key_off[1] : (size_t)Lv;
+        enc_ctx.p[0] = m->enc.p[0] + ctx_row * D;
+        enc_ctx.p[1] = NP == 2 ? m->enc.p[1] + ctx_row * D : nullptr;
         norm<NP>(c, m->ex, m->ctx_enc.final_ln, rows, D, nullptr, 0, 0, &enc_ctx, nullptr);
         HIP_TRY(m, hipStreamSynchronize(s));
       }
@@ -783,23 +792,32 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
     const int Sv = Lv + Cv;
     const int Sp = round_up(Sv > 0 ? Sv : 1, 64);
     // rows [Sv, Sp) may hold normalised padding rows of the last encoder: zero them
-    if (Sp > Sv) {
+    if (m->n_cross == 1 && Sp > Sv) {
       for (int pl = 0; pl < NP; ++pl)
         HIP_TRY(m, hipMemsetAsync(m->enc.p[pl] + (size_t)Sv * D, 0,
                                   (size_t)(m->S_pad - Sv) * D * sizeof(bf16_t), s));
     }
-    // S2: cross-attention K / V^T of every decoder layer, once per segment
-    for (int l = 0; l < m->Ld; ++l) {
-      EpiQKV<NP> ek;
-      const size_t koff = ((size_t)l * m->Bmax + b) * m->S_pad * J;
-      ek.qk[0] = m->kc.p[0] + koff; ek.qk[1] = m->kc.p[NP - 1] + koff;
-      ek.vt[0] = m->vtc.p[0] + koff; ek.vt[1] = m->vtc.p[NP - 1] + koff;
-      ek.ld_qk = J; ek.v_start = J; ek.seg_len = m->S_pad; ek.vt_ld = m->S_pad; ek.vt_rows = J;
-      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->enc, D, m->dec[l].wkv_cross, D, Sp, 2 * J, D, ek, ek.v_start);
-    }
-    m->h_nkeys_cross[b] = Sv;
+    // S2: cross-attention K / V^T of every decoder layer, once per segment; one projection per key region
+    // (concat_encodings: one region = both encodings, network.py:217-230; sum_cross_attends: a module and a
+    // region per encoding, :199-216)
+    const int reg_rows[2] = {m->n_cross == 2 ? Lv : Sv, Cv};
+    for (int l = 0; l < m->Ld; ++l)
+      for (int e = 0; e < m->n_cross; ++e) {
+        if (reg_rows[e] == 0) continue;   // no valid key: the attention kernel never reads this region
+        EpiQKV<NP> ek;
+        const size_t koff = ((size_t)l * m->Bmax + b) * m->S_pad * J;
+        const size_t r0 = (size_t)m->key_off[e];
+        ek.qk[0] = m->kc.p[0] + koff + r0 * J; ek.qk[1] = m->kc.p[NP - 1] + koff + r0 * J;
+        ek.vt[0] = m->vtc.p[0] + koff + r0; ek.vt[1] = m->vtc.p[NP - 1] + koff + r0;
+        ek.ld_qk = J; ek.v_start = J; ek.seg_len = m->S_pad; ek.vt_ld = m->S_pad; ek.vt_rows = J;
+        Planes a;
+        a.p[0] = m->enc.p[0] + r0 * D;
+        a.p[1] = NP == 2 ? m->enc.p[1] + r0 * D : nullptr;
+        gemm<NP, TK_QKV>(c, KC_GEMM_QKV, a, D, m->dec[l].wkv_cross[e], D, round_up(reg_rows[e], 64), 2 * J, D, ek, ek.v_start);
+      }
+    for (int e = 0; e < m->n_cross; ++e) m->h_nkeys_cross[(size_t)e * m->Bmax + b] = reg_rows[e];
   }
-  HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_cross, m->h_nkeys_cross.data(), batch * sizeof(int),
+  HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_cross, m->h_nkeys_cross.data(), m->h_nkeys_cross.size() * sizeof(int),
                             hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipStreamSynchronize(s));
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "encode failed: %s", hipGetErrorString(c.err));
@@ -831,7 +849,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
       EpiStoreBf16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
-      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross, D, BT, J, D, es);
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross[0], D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
@@ -839,7 +857,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
       attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
                     (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
-      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross, J, BT, D, J, EpiResidual{m->x, D});
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross[0], J, BT, D, J, EpiResidual{m->x, D});
     }
     norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
     EpiGeglu<NP> eg;
@@ -849,6 +867,16 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
   }
   norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
   gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
+}
+
+// The key split exists to fill the chip when heads x query groups alone cannot (48 blocks at one song); with
+// several songs per handle the (head, query group, song) blocks already cover the CUs, and every split costs a
+// partial round trip + the merge launch: split only as far as ~192 blocks need.
+inline int cross_ksplit_for(const msd_model* m, int batch) {
+  if (m->cross_ksplit_fixed) return m->cross_ksplit;
+  const int blocks = m->H * (m->T / 64) * batch;
+  int ks = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
+  return ks < m->cross_ksplit ? ks : m->cross_ksplit;
 }
 
 template <int NP>
@@ -914,21 +942,40 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
-      EpiStoreBf16<NP> es;
-      es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
-      es.rsc = rowscale(nullptr, 0);
-      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross, D, BT, J, D, es);
+      // every module projects its queries from the SAME normed input (network.py:196-198), so all query
+      // projections run before the first output projection rewrites y
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
-      const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
-      Planes vt;
-      vt.p[0] = m->vtc.p[0] + loff;
-      vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
-      attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
-                    (size_t)J * m->S_pad, ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
-      EpiResidualNorm<NP> ec = er;
-      ec.g_lo = g_tab(2 * l + 1); ec.g_lo_stride = slots * D; ec.g_hi = nullptr; ec.g_hi_stride = 0;
-      ec.split_row = BT;
-      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, ao, J, w.wo_cross, J, BT, D, J, ec);
+      for (int e = 0; e < m->n_cross; ++e) {
+        const Planes& cq = e == 0 ? m->cq : m->cq2;
+        EpiStoreBf16<NP> es;
+        es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
+        es.rsc = rowscale(nullptr, 0);
+        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross[e], D, BT, J, D, es);
+      }
+      for (int e = 0; e < m->n_cross; ++e) {
+        const size_t r0 = (size_t)m->key_off[e];
+        const bf16_t* kc[2] = {m->kc.p[0] + loff + r0 * J, m->kc.p[NP - 1] + loff + r0 * J};
+        Planes vt;
+        vt.p[0] = m->vtc.p[0] + loff + r0;
+        vt.p[1] = NP == 2 ? m->vtc.p[1] + loff + r0 : nullptr;
+        const int region = (e + 1 < m->n_cross ? m->key_off[e + 1] : m->S_pad) - m->key_off[e];
+        // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
+        const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
+        const int ks = want < cap ? want : cap;
+        attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
+                      (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
+                      batch, ks, region);
+      }
+      // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
+      // other; the last one also writes the folded-norm inputs of the MLP block
+      for (int e = 0; e < m->n_cross; ++e) {
+        EpiResidualNorm<NP> ec = er;
+        const bool last_mod = e + 1 == m->n_cross;
+        ec.g_lo = last_mod ? g_tab(2 * l + 1) : nullptr; ec.g_lo_stride = last_mod ? slots * D : 0;
+        ec.g_hi = nullptr; ec.g_hi_stride = 0;
+        ec.split_row = BT;
+        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, e == 0 ? ao : m->ao2, J, w.wo_cross[e], J, BT, D, J, ec);
+      }
     }
     // (iii) MLP block (network.py:241-256)
     EpiGeglu<NP> eg;
@@ -1116,6 +1163,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   }
   // encode_impl writes round_up(Lv, 64) token rows and then round_up(Cv, 64) context rows from row Lv
   m->S_pad = round_up(m->L, 64) + round_up(m->C, 64);
+  // decoder_cross_attend_style (network.py:199-235): with one encoding both styles are the same module
+  m->n_cross = (cfg->cross_attend_sum && cfg->has_context) ? 2 : 1;
+  m->key_off[0] = 0; m->key_off[1] = round_up(m->L, 64);
+  if (m->n_cross == 2 && !m->fold_norm) return bad("sum_cross_attends needs the folded-norm path (MSD_FOLD_NORM=1)");
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
   declare_weights(m);
   *out = m;
@@ -1137,7 +1188,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
   m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
-  if (const char* v = getenv("MSD_CROSS_KSPLIT")) m->cross_ksplit = atoi(v) > 0 ? atoi(v) : 1;
+  if (const char* v = getenv("MSD_CROSS_KSPLIT")) { m->cross_ksplit = atoi(v) > 0 ? atoi(v) : 1; m->cross_ksplit_fixed = true; }
   TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
   TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
   TRY(palloc(m, &m->h, Mmax * D));
@@ -1145,6 +1196,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(palloc(m, &m->vt, Mmax * J));
   TRY(palloc(m, &m->ao, Mmax * J));
   TRY(palloc(m, &m->cq, (size_t)m->Bmax * T * J));
+  if (m->n_cross == 2) {
+    TRY(palloc(m, &m->cq2, (size_t)m->Bmax * T * J));
+    TRY(palloc(m, &m->ao2, (size_t)m->Bmax * T * J));
+  }
   TRY(palloc(m, &m->g, Mmax * F));
   TRY(dalloc(m, &m->h32, Mmax * D));
   TRY(dalloc(m, &m->eps, Mmax * m->ND));
@@ -1154,8 +1209,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
   TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
-  TRY(dalloc(m, &m->d_nkeys_cross, (size_t)m->Bmax));
-  m->h_nkeys_cross.assign(m->Bmax, 0);
+  TRY(dalloc(m, &m->d_nkeys_cross, (size_t)2 * m->Bmax));
+  m->h_nkeys_cross.assign((size_t)m->n_cross * m->Bmax, 0);
   {
     std::vector<int> nk((size_t)m->passes * m->Bmax, T);
     HIP_TRY(m, hipMemcpy(m->d_nkeys_self, nk.data(), nk.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1253,14 +1308,16 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     w.ln_cross = W(m, lp + "/pre_cross_attention_layer_norm/scale");
     w.ln_mlp = W(m, lp + "/pre_mlp_layer_norm/scale");
     if ((rc = pack_attention(m, s, lp + "/self_attention", w.self))) return rc;
-    const std::string cp = lp + "/MultiHeadDotProductAttention_0";
-    if ((rc = palloc(m, &w.wq_cross, (size_t)J * D))) return rc;
-    if ((rc = palloc(m, &w.wkv_cross, (size_t)2 * J * D))) return rc;
-    if ((rc = palloc(m, &w.wo_cross, (size_t)D * J))) return rc;
-    if ((rc = pack(m, s, W(m, cp + "/query/kernel"), D, J, w.wq_cross, 0, 0))) return rc;
-    if ((rc = pack(m, s, W(m, cp + "/key/kernel"), D, J, w.wkv_cross, 0, 0))) return rc;
-    if ((rc = pack(m, s, W(m, cp + "/value/kernel"), D, J, w.wkv_cross, J, 0))) return rc;
-    if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross, 0, 0))) return rc;
+    for (int e = 0; e < m->n_cross; ++e) {
+      const std::string cp = lp + "/MultiHeadDotProductAttention_" + std::to_string(e);
+      if ((rc = palloc(m, &w.wq_cross[e], (size_t)J * D))) return rc;
+      if ((rc = palloc(m, &w.wkv_cross[e], (size_t)2 * J * D))) return rc;
+      if ((rc = palloc(m, &w.wo_cross[e], (size_t)D * J))) return rc;
+      if ((rc = pack(m, s, W(m, cp + "/query/kernel"), D, J, w.wq_cross[e], 0, 0))) return rc;
+      if ((rc = pack(m, s, W(m, cp + "/key/kernel"), D, J, w.wkv_cross[e], 0, 0))) return rc;
+      if ((rc = pack(m, s, W(m, cp + "/value/kernel"), D, J, w.wkv_cross[e], J, 0))) return rc;
+      if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross[e], 0, 0))) return rc;
+    }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
   }
   m->dec_final_ln = W(m, "decoder/decoder_norm/scale");

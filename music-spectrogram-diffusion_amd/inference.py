@@ -79,10 +79,7 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
   t5, d = spec.t5, spec.diffusion
   # Everything the kernels fix by construction is validated here with the
   # reference's own error type (ValueError; msd_amd.h msd_config comment).
-  if t5.decoder_cross_attend_style != 'concat_encodings':
-    if t5.decoder_cross_attend_style == 'sum_cross_attends':
-      raise NotImplementedError('decoder_cross_attend_style=sum_cross_attends is not selected '
-                                'by any shipped gin and is not built')
+  if t5.decoder_cross_attend_style not in ('concat_encodings', 'sum_cross_attends'):   # network.py:236-238
     raise ValueError(f'Unknown decoder_cross_attend_style: {t5.decoder_cross_attend_style}')
   if tuple(t5.mlp_activations) != ('gelu', 'linear'):
     raise NotImplementedError('only gated-GELU MLPs (mlp_activations=(gelu, linear)) are built')
@@ -150,6 +147,7 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
   cfg.train_schedule = native.SCHEDULES[ts.name]
   cfg.train_schedule_start, cfg.train_schedule_stop = float(ts.start or 0.0), float(ts.stop or 0.0)
   cfg.train_schedule_num_steps = int(ts.num_steps or 0)
+  cfg.cross_attend_sum = int(t5.decoder_cross_attend_style == 'sum_cross_attends')
   return cfg
 
 

@@ -63,7 +63,7 @@ class MsdConfig(ctypes.Structure):
       ('sampler_schedule', ctypes.c_int32), ('sampler_schedule_start', ctypes.c_float),
       ('sampler_schedule_stop', ctypes.c_float), ('train_schedule', ctypes.c_int32),
       ('train_schedule_start', ctypes.c_float), ('train_schedule_stop', ctypes.c_float),
-      ('train_schedule_num_steps', ctypes.c_int32)]
+      ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32)]
 
 
 _lib = None

@@ -44,7 +44,8 @@ class FastModel:
 
   def __init__(self, xp, cfg, diffusion_config, params, context, precision='f32',
                codec=None):
-    assert cfg.decoder_cross_attend_style == 'concat_encodings'
+    assert cfg.decoder_cross_attend_style in ('concat_encodings', 'sum_cross_attends')
+    self.sum_style = cfg.decoder_cross_attend_style == 'sum_cross_attends'
     assert diffusion_config.model_output in ('eps', 'x0', 'v')
     assert diffusion_config.sampler.name in ('ddpm', 'ddim')
     self.xp, self.cfg, self.dc = xp, cfg, diffusion_config
@@ -159,12 +160,12 @@ class FastModel:
     tokens = np.asarray(tokens)
     self.kv = []
     for b in range(tokens.shape[0]):
-      enc_rows = []
+      tok_enc = ctx_enc = None
       valid = np.nonzero(tokens[b] > 0)[0]
       if valid.size:
         x = xp.take(p[self.tok + '/token_embedder/embedding'], xp.asint(tokens[b][valid]))
         x = x + xp.take(p[self.tok + '/Embed_0/embedding'], xp.asint(valid))
-        enc_rows.append(self._encoder_stack(self.tok, x))
+        tok_enc = self._encoder_stack(self.tok, x)
       if self.context:
         cm = np.asarray(ctx_mask[b])
         cvalid = np.nonzero(cm > 0)[0]
@@ -182,17 +183,25 @@ class FastModel:
             pos = np.arange(cm.shape[0])
           x = x + xp.take(p['continuous_encoder/Embed_0/embedding'], xp.asint(pos))
           x = xp.take(x, xp.asint(cvalid))
-          enc_rows.append(self._encoder_stack('continuous_encoder', x))
-      if not enc_rows:
-        self.kv.append(None)
-        continue
-      enc = xp.concatenate(enc_rows, 0)
-      layers = []
-      for l in range(cfg.num_decoder_layers):
-        ap = 'decoder/layers_%d/MultiHeadDotProductAttention_0' % l
-        layers.append((self._heads(self.rq(self.mm(enc, ap + '/key/kernel'))),
-                       self._heads(self.rq(self.mm(enc, ap + '/value/kernel')))))
-      self.kv.append(layers)
+          ctx_enc = self._encoder_stack('continuous_encoder', x)
+      # key regions, one cross-attention module each: concat_encodings = ONE region holding both encodings
+      # (network.py:217-235); sum_cross_attends = a module per encoding, outputs summed (:199-216)
+      if self.sum_style:
+        regions = [(0, tok_enc), (1, ctx_enc)] if self.context else [(0, tok_enc)]
+      else:
+        both = [e for e in (tok_enc, ctx_enc) if e is not None]
+        regions = [(0, xp.concatenate(both, 0) if both else None)]
+      mods = []
+      for e, enc in regions:
+        if enc is None:
+          continue   # no valid key: zero_activations_if_masked makes the module's output exactly 0
+        layers = []
+        for l in range(cfg.num_decoder_layers):
+          ap = 'decoder/layers_%d/MultiHeadDotProductAttention_%d' % (l, e)
+          layers.append((self._heads(self.rq(self.mm(enc, ap + '/key/kernel'))),
+                         self._heads(self.rq(self.mm(enc, ap + '/value/kernel')))))
+        mods.append((e, layers))
+      self.kv.append(mods or None)
 
   # -- one decoder pass --------------------------------------------------------
   def decoder_pass(self, z, i, cond):
@@ -211,12 +220,15 @@ class FastModel:
         h = h * (sb[:d] + 1.0) + sb[d:]
         x = x + self._self_attention(lp + '/self_attention', h)
         if cond and self.kv[b] is not None:  # S4
-          ap = lp + '/MultiHeadDotProductAttention_0'
           h = ops.rms_layer_norm(xp, x, p[lp + '/pre_cross_attention_layer_norm/scale'])
-          q = self._heads(self.rq(self.mm(h, ap + '/query/kernel')))
-          k, v = self.kv[b][l]
-          a = self.rq(self._attend(q, k, v))
-          x = x + self.mm(a, ap + '/out/kernel')
+          upd = None
+          for e, layers in self.kv[b]:
+            ap = lp + '/MultiHeadDotProductAttention_%d' % e
+            q = self._heads(self.rq(self.mm(h, ap + '/query/kernel')))
+            k, v = layers[l]
+            o = self.mm(self.rq(self._attend(q, k, v)), ap + '/out/kernel')
+            upd = o if upd is None else upd + o
+          x = x + upd
         sb = self.film[l][1][i]
         h = ops.rms_layer_norm(xp, x, p[lp + '/pre_mlp_layer_norm/scale'])
         h = h * (sb[:d] + 1.0) + sb[d:]

@@ -376,3 +376,43 @@ def test_xcd_resident_chain_kernel_matches_separate_launches(monkeypatch):
   ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
   ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
   helpers.assert_fp32_class(outs['1'], ref64, ref32, 'chain')
+
+
+@pytest.mark.parametrize('preset,mask', [('tiny_context', 'ragged'), ('tiny_context', 'zeros'), ('tiny', 'ones')])
+def test_sum_cross_attends_style(preset, mask):
+  """decoder_cross_attend_style='sum_cross_attends' (the T5Config dataclass default, network.py:199-216): one
+  cross-attention module per encoding (own q/k/v/out kernels, own key region and key count in the cache),
+  outputs summed into the residual.  Single decoder passes elementwise against the float64 oracle, then a
+  sampled segment with the float32 oracle as yardstick."""
+  import dataclasses
+  import torch
+  from oracle import backend, fast
+  spec = msd_amd.config.preset(preset, num_steps=6)
+  spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style='sum_cross_attends'))
+  params = msd_amd.synthetic.init_params(spec, 8, norm_scale_jitter=0.1)
+  model = msd_amd.InferenceModel(params, spec, batch_size=2)
+  nm = model._get_native()
+  batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)
+  cfg, dc = helpers.oracle_configs(spec)
+  fm = fast.FastModel(backend.NumpyBackend('float64'), cfg, dc, params, spec.has_context)
+  if spec.has_context:
+    fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+    nm.encode(2, batch['encoder_input_tokens'], torch.as_tensor(batch['encoder_continuous_inputs']).cuda(),
+              batch['encoder_continuous_mask'])
+  else:
+    fm.encode(batch['encoder_input_tokens'])
+    nm.encode(2, batch['encoder_input_tokens'])
+  z = np.random.default_rng(0).standard_normal((2, 64, 128)).astype(np.float32)
+  zd = torch.as_tensor(z).cuda()
+  for step, cond in [(5, True), (1, True), (2, False)]:
+    eps = torch.zeros_like(zd)
+    nm.decoder_pass(2, step, zd, cond, eps)
+    torch.cuda.synchronize()
+    want = fm.decoder_pass(z.astype(np.float64), step, cond)
+    err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 2e-4, (preset, mask, step, cond, err)
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  got, _ = model.predict(batch, init_z=init_z, noise=noise)
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  helpers.assert_fp32_class(got, ref64, ref32, 'sum_cross_attends %s/%s' % (preset, mask))

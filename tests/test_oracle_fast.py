@@ -23,6 +23,24 @@ def test_fast_equals_faithful_float64(preset, mask):
   np.testing.assert_allclose(got, ref, atol=1e-9)
 
 
+@pytest.mark.parametrize('preset,mask', [('tiny', 'ones'), ('tiny_context', 'zeros'), ('tiny_context', 'ragged')])
+def test_fast_equals_faithful_sum_cross_attends(preset, mask):
+  """decoder_cross_attend_style='sum_cross_attends' (the T5Config default, network.py:199-216): one
+  cross-attention module per encoding; the shortcuts (cached K/V per module, dropped padding, S4) hold."""
+  import dataclasses
+  spec = msd_amd.config.preset(preset, num_steps=5)
+  spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style='sum_cross_attends'))
+  params = msd_amd.synthetic.init_params(spec, 1, norm_scale_jitter=0.1)
+  assert ('decoder/layers_0/MultiHeadDotProductAttention_1/query/kernel' in params) == spec.has_context
+  batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.NumpyBackend('float64')
+  ref, _ = predict.predict_batch_with_aux(xp, cfg, dc, params, batch, init_z, noise, context=spec.has_context)
+  got, _ = fast.FastModel(xp, cfg, dc, params, spec.has_context).predict(batch, init_z, noise)
+  np.testing.assert_allclose(got, ref, atol=1e-9)
+
+
 def test_fast_torch_backend_and_bf16x3_close_to_f32():
   spec = msd_amd.config.preset('tiny_context', num_steps=5)
   params = msd_amd.synthetic.init_params(spec, 1)
