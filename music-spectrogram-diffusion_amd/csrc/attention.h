@@ -51,6 +51,7 @@ struct AttnParams {
   float* part_o;        // [ksplit][rows][heads*64]
   float* part_ml;       // [ksplit][rows][heads][2]
   int total_rows;       // rows of q over all segments
+  WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_bf16.h)
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag8;
@@ -282,6 +283,12 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
+  PrefetchRegs pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_bf16.h WeightPrefetch)
+  {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int nlin = gridDim.x * gridDim.y * gridDim.z;
+    prefetch_weights(p.pf, lin & 7, lin >> 3, (nlin + 7) >> 3, p.q[0], pf_keep);
+  }
 
   // ---- merge the 4 key-group partials of each query block through LDS --------------
   // per wave: O [32 q][64 d + 4 pad] fp32, then m[32], l[32]
@@ -341,6 +348,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
       }
     }
   }
+  prefetch_done(pf_keep);
 }
 
 // Finish a key-split attention: out[row][head*64 + d] = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m)

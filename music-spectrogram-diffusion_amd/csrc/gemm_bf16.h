@@ -28,11 +28,94 @@
 
 namespace msd {
 
+// Warm a LATER launch's packed weights in this XCD's L2.  A DDPM step touches every weight matrix once per
+// 1.2 ms, so each GEMM starts on HBM-cold operands (+1.5 .. 2 us per launch against L2-warm ones,
+// tools/ubench/gemm_bench.hip).  The weights do not depend on anything computed in the step, and the
+// consumer's block -> XCD map is known (gemm_bf16_dma_kernel): every block of the PRODUCER launch, once its main
+// loop is done, touches its share of the W^T rows that the consumer's blocks on the same XCD will read -- one
+// 4-byte load per 128-byte line, nobody reads the data.
+struct WeightPrefetch {
+  const bf16_t* base[2] = {nullptr, nullptr};   // planes of the consumer's packed W^T [rows][K]
+  int rows = 0;        // 0 = nothing to do
+  int row_bytes = 0;   // K * 2
+  int bn = 32;         // the consumer's column tile
+  int cx = 4;          // the consumer's XCD column groups (8 / xcd_rows): XCD x reads tiles bn_i = x % cx (mod cx)
+  // host-computed helpers (set_geometry): the index math below must stay a handful of instructions -- it sits
+  // between the main loop and the epilogue of every launch (a first version with integer divisions cost
+  // +1 us per launch, more than the prefetch wins)
+  int lg = 4;          // log2 of the per-row line slots (12 lines -> 16 slots, 32 -> 32)
+  int lpr = 12;        // 128-byte lines per row
+  uint32_t bn_magic = 0;   // ceil(2^32 / bn): v / bn == umulhi(v, bn_magic) for v < 2^16
+  void set_geometry() {
+    lpr = row_bytes >> 7;
+    lg = 0;
+    while ((1 << lg) < lpr) ++lg;
+    bn_magic = (uint32_t)((0x100000000ull + (uint64_t)bn - 1) / (uint64_t)bn);
+  }
+};
+
+// xcd / blk / nblk: this block's XCD, its index among and the number of the launch's blocks on that XCD.
+// The touches are plain 4-byte loads issued from inline asm into registers nobody reads: the compiler does not
+// know they are loads, so it never waits for them (an LDS-DMA touch would be waited for in front of the
+// epilogue's first LDS read); `keep` pins the destination registers until prefetch_done() at the end of the
+// kernel, and s_endpgm waits for outstanding loads by itself.  At most kPrefetchPerThread lines per thread.
+constexpr int kPrefetchPerThread = 3;   // touches per wave: covers every share of the decoder's plan (msd_api.hip)
+struct PrefetchRegs { uint32_t r[kPrefetchPerThread]; };
+
+// `valid`: any mapped device address (touched instead when there is nothing to prefetch: the function has ONE
+// path, so the destination registers reach prefetch_done() without a copy or a merge of values)
+__device__ __forceinline__ void prefetch_weights(const WeightPrefetch& pf, int xcd, int blk, int nblk, const void* valid,
+                                                 PrefetchRegs& keep) {
+#ifdef MSD_NO_PREFETCH   // A/B build without the feature (tools/ab_bench.sh)
+#pragma unroll
+  for (int u = 0; u < kPrefetchPerThread; ++u) keep.r[u] = 0;
+  return;
+#endif
+  if (pf.rows <= 0) {   // nothing to warm (block-uniform): no loads at all.  tools/check_prefetch_regs.py verifies on
+                        // the compiled listing that the two paths did not make the compiler copy or reuse `keep`
+#pragma unroll
+    for (int u = 0; u < kPrefetchPerThread; ++u) keep.r[u] = 0;
+    return;
+  }
+  // Share of this XCD: the column tiles t = xc, xc + cx, ... of the consumer -> `rows_x` rows per plane.  One
+  // wave-wide touch covers 64 >> lg whole rows (lane = (row offset, line slot)), so everything up to the first
+  // row of a touch is wave-uniform SCALAR arithmetic and a lane adds its row offset and line: the index math
+  // sits between the main loop and the epilogue of every launch and must stay a few VALU instructions (a first
+  // version with per-lane divisions cost +1 us per launch, more than the prefetch wins).  Waves are dealt
+  // block-cyclically: touch u of wave w of block `blk` starts at row ((blk + nblk * u) * nwave + w) * rows-per-touch.
+  const int cx = pf.cx, xc = xcd & (cx - 1);                         // cx is 4 or 8
+  const int ntile = (int)__umulhi((uint32_t)pf.rows, pf.bn_magic);
+  const int ntile_x = (ntile - xc + cx - 1) >> (cx == 8 ? 3 : 2);     // (ntile - xc + cx - 1) >= 0
+  const int rows_x = ntile_x * pf.bn;
+  const int planes = pf.base[1] && pf.base[1] != pf.base[0] ? 2 : 1;
+  const int total_rows = pf.rows > 0 ? rows_x * planes : 0;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nwave = (int)blockDim.x >> 6;
+  const int lane = (int)threadIdx.x & 63, rpt = 64 >> pf.lg;         // rows per touch: 4 (12 lines) or 2 (32 lines)
+  const int sub = lane >> pf.lg, line = lane & ((1 << pf.lg) - 1);
+  const uint32_t lane_off = (uint32_t)sub * (uint32_t)pf.row_bytes + (uint32_t)line * 128u;
+  const bool lane_in = line < pf.lpr;
+#pragma unroll
+  for (int u = 0; u < kPrefetchPerThread; ++u) {
+    const int rp0 = ((blk + nblk * u) * nwave + wave) * rpt;          // scalar from here ...
+    const int pl = rp0 >= rows_x ? 1 : 0, rv0 = rp0 - pl * rows_x;     // (rows_x and bn are multiples of rpt:
+    const int ti = (int)__umulhi((uint32_t)rv0, pf.bn_magic);          //  a touch never straddles a tile or a plane)
+    const int row0 = (xc + cx * ti) * pf.bn + (rv0 - ti * pf.bn);
+    const char* row_ptr = reinterpret_cast<const char*>(pf.base[pl]) + (size_t)row0 * pf.row_bytes;   // ... to here
+    const char* src = (rp0 < total_rows && lane_in) ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(keep.r[u]) : "v"(src) : "memory");
+  }
+}
+__device__ __forceinline__ void prefetch_done(const PrefetchRegs& keep) {
+#pragma unroll
+  for (int u = 0; u < kPrefetchPerThread; ++u) asm volatile("" ::"v"(keep.r[u]));
+}
+
 struct GemmParams {
   const bf16_t* A[2];
   const bf16_t* B[2];
   int lda, ldb;
   int M, N, K;
+  WeightPrefetch pf;  // optional: warm a later launch's weights (see WeightPrefetch)
   int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
 };
@@ -299,6 +382,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_D_READ
 #undef MSD_D_ISSUE
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
+  // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
+  PrefetchRegs pf_keep;
+  prefetch_weights(p.pf, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3, p.B[0], pf_keep);
 
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
@@ -311,6 +397,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
   __syncthreads();
   epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true);
+  prefetch_done(pf_keep);
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>

@@ -158,6 +158,7 @@ struct msd_model {
   bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
   // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
   bool chain_mlp = false;
+  bool prefetch = true;        // producers warm the next GEMM's weights in L2 (MSD_PREFETCH=0: off)
   int cus = 0;                 // compute units of the device (chain grid = one block per CU)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
@@ -320,9 +321,10 @@ enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3, TK_SQUARE
 
 template <int NP, int BM, int BN, int NS, class Epi>
 void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
-            const Epi& epi) {
+            const Epi& epi, const WeightPrefetch* pf = nullptr) {
   c.begin(kc);
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
   // XCD grid (gemm_bf16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
   // (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
   // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
@@ -367,41 +369,74 @@ inline int big_m_threshold() {   // rows from which the 128-row tiles are used (
   return v;
 }
 
-template <int NP, int TK, class Epi>
-void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
-          const Epi& epi, int align = 0) {
+// The tile a GEMM of kind TK runs on, (BM, BN): ONE rule for the launch below and for whoever prefetches that
+// launch's weights (the prefetcher needs the consumer's column tile and XCD grid).
+struct TileShape { int bm, bn; };
+template <int NP, int TK>
+TileShape pick_tile(int M, int N, int align) {
   const bool big = NP == 2 && M >= big_m_threshold() && M % 128 == 0;
-  if constexpr (TK == TK_QKV) {
-    if constexpr (NP == 2) {
-      if (big && N % 96 == 0 && align % 96 == 0)
-        return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+  if (TK == TK_QKV) {
+    if (NP == 2) {
+      if (big && N % 96 == 0 && align % 96 == 0) return {128, 96};
       // 64 x 96 = one block per CU at base (192 blocks); at the small model (N = 1152: 96 blocks)
       // 64 x 64 fills the chip better
-      if (N % 96 == 0 && align % 96 == 0 && tile_cost(M, N, 64, 96) <= tile_cost(M, N, 64, 64))
-        return gemm_t<NP, 64, 96, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+      if (N % 96 == 0 && align % 96 == 0 && tile_cost(M, N, 64, 96) <= tile_cost(M, N, 64, 64)) return {64, 96};
     }
-    return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    return {64, 64};
   }
-  else if constexpr (TK == TK_MLP_IN) {
+  if (TK == TK_MLP_IN) {
+    if (NP == 2) {
+      if (big && N % 128 == 0) return {128, 128};
+      if (N % 128 == 0 && tile_cost(M, N, 64, 128) <= tile_cost(M, N, 64, 64)) return {64, 128};
+    }
+    return {64, 64};
+  }
+  if (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE) && big && N % 96 == 0) return {128, 96};   // N = D projections of a decoder layer
+  if (TK == TK_TALL && M % 64 == 0 && tile_cost(M, N, 64, kNarrowTile) <= tile_cost(M, N, kNarrowTile, kNarrowTile))
+    return {64, kNarrowTile};
+  return {kNarrowTile, kNarrowTile};
+}
+
+template <int NP, int TK, class Epi>
+void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
+          const Epi& epi, int align = 0, const WeightPrefetch* pf = nullptr) {
+  const TileShape t = pick_tile<NP, TK>(M, N, align);
+#define MSD_GO(BM_, BN_, NS_) return gemm_t<NP, BM_, BN_, NS_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf)
+  if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
-      if (big && N % 128 == 0)
-        return gemm_t<NP, 128, 128, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
-      if (N % 128 == 0 && tile_cost(M, N, 64, 128) <= tile_cost(M, N, 64, 64))
-        return gemm_t<NP, 64, 128, 3, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+      if (t.bm == 128) MSD_GO(128, 96, 2);
+      if (t.bn == 96) MSD_GO(64, 96, 3);
     }
-    return gemm_t<NP, 64, 64, wide_ns(NP), Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
-  }
-  else {
-    if constexpr (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE)) {   // the N = D projections of a decoder layer
-      if (big && N % 96 == 0)
-        return gemm_t<NP, 128, 96, 2, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    MSD_GO(64, 64, wide_ns(NP));
+  } else if constexpr (TK == TK_MLP_IN) {
+    if constexpr (NP == 2) {
+      if (t.bm == 128) MSD_GO(128, 128, 2);
+      if (t.bn == 128) MSD_GO(64, 128, 3);
+    }
+    MSD_GO(64, 64, wide_ns(NP));
+  } else {
+    if constexpr (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE)) {
+      if (t.bm == 128) MSD_GO(128, 96, 2);
     }
     if constexpr (TK == TK_TALL) {
-      if (M % 64 == 0 && tile_cost(M, N, 64, kNarrowTile) <= tile_cost(M, N, kNarrowTile, kNarrowTile))
-        return gemm_t<NP, 64, kNarrowTile, kTallNS, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+      if (t.bm == 64) MSD_GO(64, kNarrowTile, kTallNS);
     }
-    return gemm_t<NP, kNarrowTile, kNarrowTile, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+    MSD_GO(kNarrowTile, kNarrowTile, 4);
   }
+#undef MSD_GO
+}
+
+// What a producer launch needs to know to warm the weights `w` [N, K] of a later GEMM of kind TK on M rows
+template <int NP, int TK>
+WeightPrefetch prefetch_of(const msd_model* m, const Planes& w, int M, int N, int K, int align = 0) {
+  WeightPrefetch pf;
+  if (!m->prefetch || NP != 2) return pf;
+  const TileShape t = pick_tile<NP, TK>(M, N, align);
+  const int rx = ((M / t.bm) % 2 == 0) ? 2 : 1;   // gemm_t's default XCD grid: 2 row groups when they divide
+  pf.base[0] = w.p[0]; pf.base[1] = w.p[1];
+  pf.rows = N; pf.row_bytes = K * 2; pf.bn = t.bn; pf.cx = 8 / rx;
+  pf.set_geometry();
+  return pf;
 }
 
 template <int NP>
@@ -450,7 +485,7 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -461,6 +496,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2
   p.vt_seg_stride = vt_seg_stride; p.k_rows = k_rows; p.vt_cols = vt_cols;
   p.ksplit = ksplit; p.part_o = c.m->att_part_o; p.part_ml = c.m->att_part_ml;
   p.total_rows = q_rows_per_seg * segs;
+  if (pf) p.pf = *pf;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -924,13 +960,22 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
     // through one norm kernel; later layers consume the folded-norm planes `y` written by the
     // previous layer's MLP output projection (inside that layer's chain launch when chains are on).
+    // Weight prefetch plan of a layer (gemm_bf16.h WeightPrefetch; every producer warms a LATER GEMM's weights
+    // behind its own epilogue): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional
+    // pass) . cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
+    const bool last_layer = (l + 1 == m->Ld);
     if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
-      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
+      const WeightPrefetch pf = prefetch_of<NP, TK_SQUARE>(m, w.self.wo, M, D, J);
+      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
     const bf16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
-    attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
-                  (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch);
+    {
+      const WeightPrefetch pf = cond0 ? prefetch_of<NP, TK_SQUARE>(m, w.wq_cross[0], BT, J, D)
+                                      : prefetch_of<NP, TK_MLP_IN>(m, w.mlp.wi, M, 2 * F, D);
+      attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
+                    (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
+    }
     // out-projection + residual; produces y for the cross-attention norm (conditional rows:
     // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
     EpiResidualNorm<NP> er;
@@ -950,7 +995,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         EpiStoreBf16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
         es.rsc = rowscale(nullptr, 0);
-        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross[e], D, BT, J, D, es);
+        const WeightPrefetch pf = prefetch_of<NP, TK_SQUARE>(m, w.wo_cross[e], BT, D, J);
+        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross[e], D, BT, J, D, es, 0, &pf);
       }
       for (int e = 0; e < m->n_cross; ++e) {
         const size_t r0 = (size_t)m->key_off[e];
@@ -962,9 +1008,11 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
         const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
         const int ks = want < cap ? want : cap;
+        const WeightPrefetch pf = (e + 1 == m->n_cross && !chain) ? prefetch_of<NP, TK_MLP_IN>(m, w.mlp.wi, M, 2 * F, D)
+                                                                  : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
-                      batch, ks, region);
+                      batch, ks, region, &pf);
       }
       // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
       // other; the last one also writes the folded-norm inputs of the MLP block
@@ -982,7 +1030,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     eg.out[0] = gb.p[0]; eg.out[1] = gb.p[NP - 1]; eg.ldc = F;
     eg.rsc = rowscale(m->d_bw_mlp + (size_t)l * 2 * F, m->Ld * 2 * F);
     EpiResidualNorm<NP> eo = er;
-    const bool last = (l + 1 == m->Ld);
+    const bool last = last_layer;
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
@@ -1003,8 +1051,13 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         continue;
       }
     }
-    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg);
-    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo);
+    {
+      const WeightPrefetch pf_out = prefetch_of<NP, TK_TALL>(m, w.mlp.wo, M, D, F);
+      gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
+      const WeightPrefetch pf_qkv = last_layer ? WeightPrefetch()
+                                               : prefetch_of<NP, TK_QKV>(m, m->dec[l + 1].self.wqkv, M, 3 * J, D, 2 * J);
+      gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
+    }
   }
   // decoder_norm + spec_out_dense (network.py:445-456).  The reference keeps this
   // projection in float32 "for stability": its output eps enters x0 = sqrt(1+e^-l)(z - s eps)
@@ -1039,7 +1092,8 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
-  gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei);
+  const WeightPrefetch pf = prefetch_of<NP, TK_QKV>(m, m->dec[0].self.wqkv, P * BT, 3 * m->J, m->D, 2 * m->J);
+  gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 
 // z (fp32) -> bf16 planes, after z was written from outside the sampler kernel
@@ -1146,6 +1200,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
   {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
@@ -1466,6 +1521,7 @@ int msd_reset_graph(msd_model* m) {
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
   m->graph_batch = 0;
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps
   return MSD_OK;
 }
 

@@ -54,7 +54,7 @@ def main():
   print('baseline %.2f us/step' % (base * 1e3), flush=True)
   best_env, best = [], base
   results = {'baseline_us': base * 1e3, 'settings': []}
-  for cls in args.classes.split(','):
+  for cls in [c for c in args.classes.split(',') if c]:
     key = 'MSD_XCD_' + cls.upper()
     cls_best = None
     for rows in (1, 2, 4, 8):
