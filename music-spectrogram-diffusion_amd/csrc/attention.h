@@ -81,7 +81,7 @@ constexpr int attention_smem() {
 // QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
 // QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
 // (decoder self-attention at B = 1: 12 heads x 4 x 2 passes = 96 blocks of 64 rows).
-template <int NP, int NS, int QB>
+template <int NP, int NS, int QB, int PF = kPfNone>
 __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams p) {
   constexpr int kRows = 32 * QB;                 // query rows per block
   constexpr int JPW = 16 / (QB * kAttKG);        // K (and V^T) DMA instructions per wave, plane and stage
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int nlin = gridDim.x * gridDim.y * gridDim.z;
-    prefetch_weights(p.pf, lin & 7, lin >> 3, (nlin + 7) >> 3, p.q[0], pf_keep);
+    prefetch_weights<PF>(p.pf, lin & 7, lin >> 3, (nlin + 7) >> 3, p.q[0], pf_keep);
   }
 
   // ---- merge the 4 key-group partials of each query block through LDS --------------
@@ -383,8 +383,11 @@ template <int NP, int NS, int QB>
 inline hipError_t attention_prepare_one() {
   constexpr int smem = attention_smem<NP, NS, QB>();
   if (smem < 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfWeights>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return a != hipSuccess ? a : b;
 }
 
 // NS: LDS ring depth (NP = 2: one stage is 64 KiB -> NS = 2; NP = 1: 32 KiB -> NS = 3)
@@ -406,12 +409,14 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   // a block, 32-row blocks (twice as many) finish sooner
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
   constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
+  const bool pfw = prefetch_kind(p.pf) == kPfWeights;   // one instantiation per prefetch kind (gemm_bf16.h)
+  const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
   if (blocks64 < 128) {
-    hipLaunchKernelGGL((attention_kernel<NP, NS, 1>), dim3(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs),
-                       dim3(kAttKG * 64), smem1, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfWeights>), g1, dim3(kAttKG * 64), smem1, stream, p);
+    else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone>), g1, dim3(kAttKG * 64), smem1, stream, p);
   } else {
-    hipLaunchKernelGGL((attention_kernel<NP, NS, 2>), dim3(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs),
-                       dim3(2 * kAttKG * 64), smem2, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfWeights>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
+    else hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfNone>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
   }
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;

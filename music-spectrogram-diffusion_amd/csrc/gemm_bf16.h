@@ -64,15 +64,16 @@ struct PrefetchRegs { uint32_t r[kPrefetchPerThread]; };
 
 // `valid`: any mapped device address (touched instead when there is nothing to prefetch: the function has ONE
 // path, so the destination registers reach prefetch_done() without a copy or a merge of values)
+// PF (compile time, so that every kernel instantiation has ONE path through here): 0 = nothing, 1 = weight tiles.
+// (Warming the cached cross-attention K / V^T from the attention-out GEMM the same way was measured and
+// dropped: the cross-attention gained 1 us per launch, the producer lost 3: profiles/r02_prefetch_ab.log.)
+enum { kPfNone = 0, kPfWeights = 1 };
+__host__ __device__ inline int prefetch_kind(const WeightPrefetch& pf) { return pf.rows > 0 ? kPfWeights : kPfNone; }
+
+template <int PF>
 __device__ __forceinline__ void prefetch_weights(const WeightPrefetch& pf, int xcd, int blk, int nblk, const void* valid,
                                                  PrefetchRegs& keep) {
-#ifdef MSD_NO_PREFETCH   // A/B build without the feature (tools/ab_bench.sh)
-#pragma unroll
-  for (int u = 0; u < kPrefetchPerThread; ++u) keep.r[u] = 0;
-  return;
-#endif
-  if (pf.rows <= 0) {   // nothing to warm (block-uniform): no loads at all.  tools/check_prefetch_regs.py verifies on
-                        // the compiled listing that the two paths did not make the compiler copy or reuse `keep`
+  if constexpr (PF == kPfNone) {
 #pragma unroll
     for (int u = 0; u < kPrefetchPerThread; ++u) keep.r[u] = 0;
     return;
@@ -164,7 +165,7 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // (gemm_bf16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
 // kernel may have produced (A planes, residual tile, row statistics): 0 in the stand-alone kernel, 16 (sc1:
 // bypass the CU's L1, served by the XCD's L2) inside the XCD-resident chain kernels (chain.h).
-template <int NP, int BM, int BN, int NS, class Epi, int CP = 0>
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int FM = WM / 16, FN = WN / 16;
@@ -384,7 +385,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
   // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
   PrefetchRegs pf_keep;
-  prefetch_weights(p.pf, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3, p.B[0], pf_keep);
+  prefetch_weights<PF>(p.pf, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3, p.B[0], pf_keep);
 
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
@@ -400,7 +401,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   prefetch_done(pf_keep);
 }
 
-template <int NP, int BM, int BN, int NS, class Epi>
+template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
 __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi ep
     bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
   }
   if (bn >= nbn || bm >= nbm) return;
-  gemm_tile<NP, BM, BN, NS, Epi, 0>(p, epi, bm, bn, smem);
+  gemm_tile<NP, BM, BN, NS, Epi, 0, PF>(p, epi, bm, bn, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -923,8 +924,11 @@ template <int NP, int BM, int BN, int NS, class Epi>
 inline hipError_t gemm_bf16_dma_prepare() {
   constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
   if (smem < 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfWeights>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return e == hipSuccess ? r : e;
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>
@@ -934,7 +938,13 @@ inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipS
   if (attr != hipSuccess) return attr;
   const int rx = p.xcd_rows, cx = 8 / rx;
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
-  hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi>), dim3(grid), dim3(256), smem, stream, p, epi);
+  switch (prefetch_kind(p.pf)) {   // one kernel instantiation per prefetch kind (single path: see prefetch_weights)
+    case kPfWeights:
+      hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfWeights>), dim3(grid), dim3(256), smem, stream, p, epi);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>), dim3(grid), dim3(256), smem, stream, p, epi);
+  }
   return hipGetLastError();
 }
 
