@@ -385,7 +385,7 @@ inline hipError_t attention_prepare_one() {
   if (smem < 64 * 1024) return hipSuccess;
   const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfWeights>),
+  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? kPfWeights : kPfNone>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return a != hipSuccess ? a : b;
 }
@@ -409,13 +409,15 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   // a block, 32-row blocks (twice as many) finish sooner
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
   constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
-  const bool pfw = prefetch_kind(p.pf) == kPfWeights;   // one instantiation per prefetch kind (gemm_bf16.h)
+  // one instantiation per prefetch kind (gemm_bf16.h); the single-plane mode never prefetches
+  constexpr int PFW = NP == 2 ? kPfWeights : kPfNone;
+  const bool pfw = NP == 2 && prefetch_kind(p.pf) == kPfWeights;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
   if (blocks64 < 128) {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfWeights>), g1, dim3(kAttKG * 64), smem1, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW>), g1, dim3(kAttKG * 64), smem1, stream, p);
     else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone>), g1, dim3(kAttKG * 64), smem1, stream, p);
   } else {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfWeights>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, PFW>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
     else hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfNone>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
   }
   if (p.ksplit > 1) {

@@ -926,7 +926,7 @@ inline hipError_t gemm_bf16_dma_prepare() {
   if (smem < 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfWeights>),
+  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, NP == 2 ? kPfWeights : kPfNone>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return e == hipSuccess ? r : e;
 }
@@ -938,13 +938,12 @@ inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipS
   if (attr != hipSuccess) return attr;
   const int rx = p.xcd_rows, cx = 8 / rx;
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
-  switch (prefetch_kind(p.pf)) {   // one kernel instantiation per prefetch kind (single path: see prefetch_weights)
-    case kPfWeights:
-      hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfWeights>), dim3(grid), dim3(256), smem, stream, p, epi);
-      break;
-    default:
-      hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>), dim3(grid), dim3(256), smem, stream, p, epi);
-  }
+  // one kernel instantiation per prefetch kind (single path: see prefetch_weights); single-plane mode: never
+  constexpr int PFW = NP == 2 ? kPfWeights : kPfNone;
+  if (NP == 2 && prefetch_kind(p.pf) == kPfWeights)
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PFW>), dim3(grid), dim3(256), smem, stream, p, epi);
+  else
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
 }
 
