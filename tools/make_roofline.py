@@ -35,7 +35,7 @@ CLASS = [
     ('32, 32, 4, msd::EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'), ('32, 32, 4, EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'),
     ('32, 32, 4, msd::EpiStoreBf16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreBf16', 'gemm_cross_q'),
     ('attention_merge_kernel', 'attn_cross_merge'),
-    ('attention_kernel<2, 2, 1>', 'attn_self'), ('attention_kernel<2, 2, 2>', 'attn_cross'),
+    ('attention_kernel<2, 2, 1', 'attn_self'), ('attention_kernel<2, 2, 2', 'attn_cross'),
     ('final_proj_f32_kernel', 'final_proj_f32'), ('EpiInProj', 'in_proj_f32'), ('sampler_step_kernel', 'sampler_step'),
 ]
 
@@ -59,20 +59,38 @@ def main():
   abytes['gemm_attn_out+gemm_cross_out'] = 0.5 * (abytes['gemm_attn_out'] + abytes['gemm_cross_out'])
   flops.setdefault('attn_cross_merge', 0.0)
   flops.setdefault('sampler_step', 0.0)
+  # a class may run as several instantiations (with / without the weight prefetch): call-weighted means
   out = {}
   with open(os.path.join(prof, '%s_bench_kernel_stats.csv' % tag)) as f:
     for r in csv.DictReader(f):
       cls = classify(r['Name'])
-      if cls and cls not in out:
-        out[cls] = {'kernel': r['Name'].split('(')[0].replace('void msd::', '').replace('msd::', ''),
-                    'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 3)}
+      if not cls:
+        continue
+      e = out.setdefault(cls, {'kernel': [], 'calls': 0, '_ns': 0.0})
+      e['kernel'].append(r['Name'].split('(')[0].replace('void msd::', '').replace('msd::', ''))
+      e['calls'] += int(r['Calls'])
+      e['_ns'] += float(r['TotalDurationNs'])
+  for e in out.values():
+    e['avg_us'] = round(e.pop('_ns') / e['calls'] / 1e3, 3)
+    e['kernel'] = ' | '.join(e['kernel'])
 
   def pmc(name):
     path = os.path.join(prof, '%s_pmc_%s.csv' % (tag, name))
     if not os.path.exists(path):
       return {}
+    acc = {}
     with open(path) as f:
-      return {classify(r['kernel']): r for r in csv.DictReader(f) if classify(r['kernel'])}
+      for r in csv.DictReader(f):
+        cls = classify(r['kernel'])
+        if not cls:
+          continue
+        n = float(r['dispatches'])
+        a = acc.setdefault(cls, {'_n': 0.0})
+        a['_n'] += n
+        for k, v in r.items():
+          if k not in ('kernel', 'dispatches'):
+            a[k] = a.get(k, 0.0) + n * float(v)
+    return {cls: {k: v / a['_n'] for k, v in a.items() if k != '_n'} for cls, a in acc.items()}
   fetch, write, sq = pmc('fetch'), pmc('write'), pmc('sq')
   for cls, e in out.items():
     us = e['avg_us']
