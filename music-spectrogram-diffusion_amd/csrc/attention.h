@@ -283,11 +283,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
-  PrefetchRegs pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_bf16.h WeightPrefetch)
+  PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_bf16.h WeightPrefetch)
   {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int nlin = gridDim.x * gridDim.y * gridDim.z;
-    prefetch_weights<PF>(p.pf, lin & 7, lin >> 3, (nlin + 7) >> 3, p.q[0], pf_keep);
+    prefetch_weights<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], pf_keep);
   }
 
   // ---- merge the 4 key-group partials of each query block through LDS --------------
@@ -385,7 +384,7 @@ inline hipError_t attention_prepare_one() {
   if (smem < 64 * 1024) return hipSuccess;
   const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? kPfWeights : kPfNone>),
+  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? 1 : 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return a != hipSuccess ? a : b;
 }
@@ -410,8 +409,8 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
   constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
   // one instantiation per prefetch kind (gemm_bf16.h); the single-plane mode never prefetches
-  constexpr int PFW = NP == 2 ? kPfWeights : kPfNone;
-  const bool pfw = NP == 2 && prefetch_kind(p.pf) == kPfWeights;
+  constexpr int PFW = NP == 2 ? 1 : 0;   // attention launches carry at most one target
+  const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
   if (blocks64 < 128) {
     if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW>), g1, dim3(kAttKG * 64), smem1, stream, p);

@@ -28,87 +28,90 @@
 
 namespace msd {
 
-// Warm a LATER launch's packed weights in this XCD's L2.  A DDPM step touches every weight matrix once per
-// 1.2 ms, so each GEMM starts on HBM-cold operands (+1.5 .. 2 us per launch against L2-warm ones,
-// tools/ubench/gemm_bench.hip).  The weights do not depend on anything computed in the step, and the
-// consumer's block -> XCD map is known (gemm_bf16_dma_kernel): every block of the PRODUCER launch, once its main
-// loop is done, touches its share of the W^T rows that the consumer's blocks on the same XCD will read -- one
-// 4-byte load per 128-byte line, nobody reads the data.
-struct WeightPrefetch {
-  const bf16_t* base[2] = {nullptr, nullptr};   // planes of the consumer's packed W^T [rows][K]
-  int rows = 0;        // 0 = nothing to do
-  int row_bytes = 0;   // K * 2
-  int bn = 32;         // the consumer's column tile
-  int cx = 4;          // the consumer's XCD column groups (8 / xcd_rows): XCD x reads tiles bn_i = x % cx (mod cx)
-  // host-computed helpers (set_geometry): the index math below must stay a handful of instructions -- it sits
-  // between the main loop and the epilogue of every launch (a first version with integer divisions cost
-  // +1 us per launch, more than the prefetch wins)
-  int lg = 4;          // log2 of the per-row line slots (12 lines -> 16 slots, 32 -> 32)
-  int lpr = 12;        // 128-byte lines per row
-  uint32_t bn_magic = 0;   // ceil(2^32 / bn): v / bn == umulhi(v, bn_magic) for v < 2^16
-  void set_geometry() {
-    lpr = row_bytes >> 7;
+// Warm what a LATER launch will read.  A DDPM step touches every weight matrix (and each layer's cached
+// cross-attention K / V^T) once per 1.1 ms, so every launch started on HBM-cold operands (+1.5 .. 2 us against
+// warm ones, tools/ubench/gemm_bench.hip).  None of that data depends on anything computed in the step: every
+// block of an EARLIER launch, once its main loop is done, touches its share of the later launch's operands --
+// one 4-byte load per 128-byte line, nobody reads the data, the latency hides behind the producer's epilogue.
+// The lines wait in the memory-side Infinity Cache: touching each line ONCE, from whatever XCD the block
+// happens to run on, measured faster than touching it from the XCDs whose blocks will read it
+// (profiles/r02_prefetch_ab.log), so a target is just a 2-D byte range shared by all blocks of the launch.
+// (Warming each layer's cached cross-attention K / V^T the same way -- from the attention-out GEMM, or from the
+// QKV GEMM three launches ahead -- was measured twice and dropped: the producer loses more than the
+// cross-attention gains.)
+struct PrefetchTarget {
+  const char* base[2] = {nullptr, nullptr};   // up to two planes with the same geometry
+  int rows = 0;            // rows per plane; 0 = unused slot
+  int row_stride = 0;      // bytes between rows
+  int lpr = 0;             // 128-byte lines to touch per row (<= 64)
+  int lg = 0;              // log2 of the line slots per row (host: smallest power of two >= lpr)
+  void set(const void* p0, const void* p1, int rows_, int row_stride_, int row_bytes) {
+    base[0] = static_cast<const char*>(p0); base[1] = static_cast<const char*>(p1);
+    rows = rows_; row_stride = row_stride_; lpr = (row_bytes + 127) >> 7;
     lg = 0;
     while ((1 << lg) < lpr) ++lg;
-    bn_magic = (uint32_t)((0x100000000ull + (uint64_t)bn - 1) / (uint64_t)bn);
   }
 };
+constexpr int kMaxPrefetchTargets = 3;
+struct WeightPrefetch {
+  PrefetchTarget t[kMaxPrefetchTargets];
+  int n = 0;   // used slots
+  void add(const PrefetchTarget& x) { if (x.rows > 0 && n < kMaxPrefetchTargets) t[n++] = x; }
+};
 
-// xcd / blk / nblk: this block's XCD, its index among and the number of the launch's blocks on that XCD.
 // The touches are plain 4-byte loads issued from inline asm into registers nobody reads: the compiler does not
 // know they are loads, so it never waits for them (an LDS-DMA touch would be waited for in front of the
 // epilogue's first LDS read); `keep` pins the destination registers until prefetch_done() at the end of the
-// kernel, and s_endpgm waits for outstanding loads by itself.  At most kPrefetchPerThread lines per thread.
-constexpr int kPrefetchPerThread = 3;   // touches per wave: covers every share of the decoder's plan (msd_api.hip)
-struct PrefetchRegs { uint32_t r[kPrefetchPerThread]; };
-
-// `valid`: any mapped device address (touched instead when there is nothing to prefetch: the function has ONE
-// path, so the destination registers reach prefetch_done() without a copy or a merge of values)
-// PF (compile time, so that every kernel instantiation has ONE path through here): 0 = nothing, 1 = weight tiles.
-// (Warming the cached cross-attention K / V^T from the attention-out GEMM the same way was measured and
-// dropped: the cross-attention gained 1 us per launch, the producer lost 3: profiles/r02_prefetch_ab.log.)
-enum { kPfNone = 0, kPfWeights = 1 };
-__host__ __device__ inline int prefetch_kind(const WeightPrefetch& pf) { return pf.rows > 0 ? kPfWeights : kPfNone; }
-
+// kernel, and s_endpgm waits for outstanding loads by itself.  kPrefetchPerThread touches per wave and target.
+// PF = number of targets, a template parameter: every kernel instantiation has ONE straight-line path through
+// here, so the destination registers reach prefetch_done() without a copy or a merge of values --
+// tools/check_prefetch_regs.py verifies that on the compiled listing (tests/test_prefetch_static.py).
+constexpr int kPrefetchPerThread = 3;
 template <int PF>
-__device__ __forceinline__ void prefetch_weights(const WeightPrefetch& pf, int xcd, int blk, int nblk, const void* valid,
-                                                 PrefetchRegs& keep) {
+struct PrefetchRegsT { uint32_t r[PF > 0 ? PF * kPrefetchPerThread : 1]; };
+enum { kPfNone = 0 };
+__host__ __device__ inline int prefetch_kind(const WeightPrefetch& pf) { return pf.n; }
+
+// blk / nblk: launch-wide index of this block and number of blocks; `valid`: any mapped device address (touched
+// by lanes that have nothing to do, so that there is no branch around a load).
+// One wave-wide touch covers 64 >> lg whole rows (lane = (row offset, line slot)): everything up to the first
+// row of a touch is wave-uniform SCALAR arithmetic and a lane adds its row offset and line.  The index math
+// sits between the main loop and the epilogue of every launch and must stay a few VALU instructions (a first
+// version with per-lane divisions cost +1 us per launch, more than the prefetch wins).  Waves are dealt
+// block-cyclically: touch u of wave w of block `blk` starts at row ((blk + nblk * u) * nwave + w) * rows-per-touch.
+template <int PF>
+__device__ __forceinline__ void prefetch_weights(const WeightPrefetch& pf, int blk, int nblk, const void* valid,
+                                                 PrefetchRegsT<PF>& keep) {
   if constexpr (PF == kPfNone) {
-#pragma unroll
-    for (int u = 0; u < kPrefetchPerThread; ++u) keep.r[u] = 0;
+    keep.r[0] = 0;
     return;
-  }
-  // Share of this XCD: the column tiles t = xc, xc + cx, ... of the consumer -> `rows_x` rows per plane.  One
-  // wave-wide touch covers 64 >> lg whole rows (lane = (row offset, line slot)), so everything up to the first
-  // row of a touch is wave-uniform SCALAR arithmetic and a lane adds its row offset and line: the index math
-  // sits between the main loop and the epilogue of every launch and must stay a few VALU instructions (a first
-  // version with per-lane divisions cost +1 us per launch, more than the prefetch wins).  Waves are dealt
-  // block-cyclically: touch u of wave w of block `blk` starts at row ((blk + nblk * u) * nwave + w) * rows-per-touch.
-  const int cx = pf.cx, xc = xcd & (cx - 1);                         // cx is 4 or 8
-  const int ntile = (int)__umulhi((uint32_t)pf.rows, pf.bn_magic);
-  const int ntile_x = (ntile - xc + cx - 1) >> (cx == 8 ? 3 : 2);     // (ntile - xc + cx - 1) >= 0
-  const int rows_x = ntile_x * pf.bn;
-  const int planes = pf.base[1] && pf.base[1] != pf.base[0] ? 2 : 1;
-  const int total_rows = pf.rows > 0 ? rows_x * planes : 0;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nwave = (int)blockDim.x >> 6;
-  const int lane = (int)threadIdx.x & 63, rpt = 64 >> pf.lg;         // rows per touch: 4 (12 lines) or 2 (32 lines)
-  const int sub = lane >> pf.lg, line = lane & ((1 << pf.lg) - 1);
-  const uint32_t lane_off = (uint32_t)sub * (uint32_t)pf.row_bytes + (uint32_t)line * 128u;
-  const bool lane_in = line < pf.lpr;
+  } else {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nwave = (int)blockDim.x >> 6;
+    const int lane = (int)threadIdx.x & 63;
 #pragma unroll
-  for (int u = 0; u < kPrefetchPerThread; ++u) {
-    const int rp0 = ((blk + nblk * u) * nwave + wave) * rpt;          // scalar from here ...
-    const int pl = rp0 >= rows_x ? 1 : 0, rv0 = rp0 - pl * rows_x;     // (rows_x and bn are multiples of rpt:
-    const int ti = (int)__umulhi((uint32_t)rv0, pf.bn_magic);          //  a touch never straddles a tile or a plane)
-    const int row0 = (xc + cx * ti) * pf.bn + (rv0 - ti * pf.bn);
-    const char* row_ptr = reinterpret_cast<const char*>(pf.base[pl]) + (size_t)row0 * pf.row_bytes;   // ... to here
-    const char* src = (rp0 < total_rows && lane_in) ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
-    asm volatile("global_load_dword %0, %1, off" : "=&v"(keep.r[u]) : "v"(src) : "memory");
+    for (int k = 0; k < PF; ++k) {
+      const PrefetchTarget& t = pf.t[k];
+      const int rows = t.rows, lpr = t.lpr;
+      const int planes = t.base[1] && t.base[1] != t.base[0] ? 2 : 1;
+      const int rpt = 64 >> t.lg;                                      // rows per touch
+      const int sub = lane >> t.lg, line = lane & ((1 << t.lg) - 1);
+      const uint32_t lane_off = (uint32_t)sub * (uint32_t)t.row_stride + (uint32_t)line * 128u;
+#pragma unroll
+      for (int u = 0; u < kPrefetchPerThread; ++u) {
+        const int rp0 = ((blk + nblk * u) * nwave + wave) * rpt;       // scalar from here ...
+        const int pl = (planes == 2 && rp0 >= rows) ? 1 : 0, row0 = rp0 - pl * rows;
+        const char* row_ptr = t.base[pl] + (size_t)row0 * t.row_stride;   // ... to here
+        const bool in = rp0 < rows * planes && row0 + sub < rows && line < lpr;
+        const char* src = in ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(keep.r[k * kPrefetchPerThread + u]) : "v"(src) : "memory");
+      }
+    }
   }
 }
-__device__ __forceinline__ void prefetch_done(const PrefetchRegs& keep) {
+template <int PF>
+__device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 #pragma unroll
-  for (int u = 0; u < kPrefetchPerThread; ++u) asm volatile("" ::"v"(keep.r[u]));
+  for (int u = 0; u < (PF > 0 ? PF * kPrefetchPerThread : 1); ++u) asm volatile("" ::"v"(keep.r[u]));
 }
 
 struct GemmParams {
@@ -384,8 +387,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_D_ISSUE
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
   // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
-  PrefetchRegs pf_keep;
-  prefetch_weights<PF>(p.pf, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3, p.B[0], pf_keep);
+  PrefetchRegsT<PF> pf_keep;
+  prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
 
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
@@ -920,15 +923,24 @@ struct EpiGeglu {
 template <int NP, int BM, int BN, int NS, class Epi>
 constexpr int gemm_bf16_dma_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN>(); }
 
-template <int NP, int BM, int BN, int NS, class Epi>
-inline hipError_t gemm_bf16_dma_prepare() {
+template <int NP, int BM, int BN, int NS, class Epi, int PF>
+inline hipError_t gemm_bf16_dma_prepare_one() {
   constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
   if (smem < 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, NP == 2 ? kPfWeights : kPfNone>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  return e == hipSuccess ? r : e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PF>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+// one-time opt-in to > 64 KiB dynamic LDS; call for every instantiation OUTSIDE stream capture
+template <int NP, int BM, int BN, int NS, class Epi>
+inline hipError_t gemm_bf16_dma_prepare() {
+  hipError_t e = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 0>(), r;
+  if constexpr (NP == 2) {   // the single-plane mode never prefetches
+    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 1>()) != hipSuccess) e = r;
+    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 2>()) != hipSuccess) e = r;
+    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 3>()) != hipSuccess) e = r;
+  }
+  return e;
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>
@@ -938,12 +950,19 @@ inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipS
   if (attr != hipSuccess) return attr;
   const int rx = p.xcd_rows, cx = 8 / rx;
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
-  // one kernel instantiation per prefetch kind (single path: see prefetch_weights); single-plane mode: never
-  constexpr int PFW = NP == 2 ? kPfWeights : kPfNone;
-  if (NP == 2 && prefetch_kind(p.pf) == kPfWeights)
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PFW>), dim3(grid), dim3(256), smem, stream, p, epi);
-  else
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, kPfNone>), dim3(grid), dim3(256), smem, stream, p, epi);
+  // one kernel instantiation per number of prefetch targets (single path: see prefetch_weights)
+#define MSD_LAUNCH_PF(PF_) \
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256), smem, stream, p, epi)
+  const int npf = NP == 2 ? prefetch_kind(p.pf) : 0;
+  if constexpr (NP == 2) {
+    if (npf == 1) MSD_LAUNCH_PF(1);
+    else if (npf == 2) MSD_LAUNCH_PF(2);
+    else if (npf >= 3) MSD_LAUNCH_PF(3);
+    else MSD_LAUNCH_PF(0);
+  } else {
+    MSD_LAUNCH_PF(0);
+  }
+#undef MSD_LAUNCH_PF
   return hipGetLastError();
 }
 

@@ -426,16 +426,17 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 #undef MSD_GO
 }
 
-// What a producer launch needs to know to warm the weights `w` [N, K] of a later GEMM of kind TK on M rows
-template <int NP, int TK>
-WeightPrefetch prefetch_of(const msd_model* m, const Planes& w, int M, int N, int K, int align = 0) {
+// Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_bf16.h PrefetchTarget)
+template <int NP>
+PrefetchTarget weights_target(const msd_model* m, const Planes& w, int N, int K) {
+  PrefetchTarget t;
+  if (m->prefetch && NP == 2) t.set(w.p[0], w.p[1], N, K * 2, K * 2);
+  return t;
+}
+template <int NP>
+WeightPrefetch prefetch_of(const msd_model* m, const Planes& w, int N, int K) {
   WeightPrefetch pf;
-  if (!m->prefetch || NP != 2) return pf;
-  const TileShape t = pick_tile<NP, TK>(M, N, align);
-  const int rx = ((M / t.bm) % 2 == 0) ? 2 : 1;   // gemm_t's default XCD grid: 2 row groups when they divide
-  pf.base[0] = w.p[0]; pf.base[1] = w.p[1];
-  pf.rows = N; pf.row_bytes = K * 2; pf.bn = t.bn; pf.cx = 8 / rx;
-  pf.set_geometry();
+  pf.add(weights_target<NP>(m, w, N, K));
   return pf;
 }
 
@@ -966,13 +967,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     const bool last_layer = (l + 1 == m->Ld);
     if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
-      const WeightPrefetch pf = prefetch_of<NP, TK_SQUARE>(m, w.self.wo, M, D, J);
+      const WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
       gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
     const bf16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
-      const WeightPrefetch pf = cond0 ? prefetch_of<NP, TK_SQUARE>(m, w.wq_cross[0], BT, J, D)
-                                      : prefetch_of<NP, TK_MLP_IN>(m, w.mlp.wi, M, 2 * F, D);
+      const WeightPrefetch pf = cond0 ? prefetch_of<NP>(m, w.wq_cross[0], J, D) : prefetch_of<NP>(m, w.mlp.wi, 2 * F, D);
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
     }
@@ -995,7 +995,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         EpiStoreBf16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
         es.rsc = rowscale(nullptr, 0);
-        const WeightPrefetch pf = prefetch_of<NP, TK_SQUARE>(m, w.wo_cross[e], BT, D, J);
+        const WeightPrefetch pf = prefetch_of<NP>(m, w.wo_cross[e], D, J);
         gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross[e], D, BT, J, D, es, 0, &pf);
       }
       for (int e = 0; e < m->n_cross; ++e) {
@@ -1008,8 +1008,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
         const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
         const int ks = want < cap ? want : cap;
-        const WeightPrefetch pf = (e + 1 == m->n_cross && !chain) ? prefetch_of<NP, TK_MLP_IN>(m, w.mlp.wi, M, 2 * F, D)
-                                                                  : WeightPrefetch();
+        const WeightPrefetch pf = (e + 1 == m->n_cross && !chain) ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
                       batch, ks, region, &pf);
@@ -1052,10 +1051,9 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       }
     }
     {
-      const WeightPrefetch pf_out = prefetch_of<NP, TK_TALL>(m, w.mlp.wo, M, D, F);
+      const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
-      const WeightPrefetch pf_qkv = last_layer ? WeightPrefetch()
-                                               : prefetch_of<NP, TK_QKV>(m, m->dec[l + 1].self.wqkv, M, 3 * J, D, 2 * J);
+      const WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
       gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
     }
   }
@@ -1092,7 +1090,7 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
-  const WeightPrefetch pf = prefetch_of<NP, TK_QKV>(m, m->dec[0].self.wqkv, P * BT, 3 * m->J, m->D, 2 * m->J);
+  const WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 

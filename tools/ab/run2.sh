@@ -6,4 +6,4 @@ for r in 1 2 3; do
   for v in prev new; do cp tools/ab/lib_$v.so $LIB; timeout 100 $B 2>/dev/null | show "$v"; done
 done
 cp tools/ab/lib_new.so $LIB
-timeout 100 python -m pytest tests/test_golden.py -m gpu -q 2>&1 | tail -1
+
