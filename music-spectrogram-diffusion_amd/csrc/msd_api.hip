@@ -1385,6 +1385,19 @@ int msd_finalize_weights(msd_model* m, void* stream) {
   hipLaunchKernelGGL(scale_rows_kernel, dim3((D * m->ND + 255) / 256), dim3(256), 0, s, m->w_spec_out,
                      m->dec_final_ln, m->w_out_g, D, m->ND);
   if ((rc = build_tables(m, s))) return rc;
+  {
+    // The weight prefetch pays only when a step streams more than the memory-side Infinity Cache (256 MB) holds:
+    // base_with_context moves 396 MB of packed decoder weights + 170 MB of cached cross K/V per step, so every
+    // launch used to start on HBM-cold operands (1.172 -> 1.09 ms/step with the prefetch); the `small` preset moves
+    // 143 MB, its weights simply stay cached from one step to the next and the touches are pure overhead
+    // (489 -> 501 ms per segment: profiles/r02_prefetch_ab.log).  MSD_PREFETCH=0/1 overrides.
+    const size_t planes = (size_t)m->NP * sizeof(bf16_t);
+    const size_t per_layer = ((size_t)3 * J * D + (size_t)D * J + (size_t)m->n_cross * 2 * ((size_t)J * D) +
+                              (size_t)2 * m->F * D + (size_t)D * m->F) * planes;
+    const size_t kv = (size_t)m->Ld * m->Bmax * m->S_pad * J * 2 * planes;
+    const size_t per_step = per_layer * m->Ld + kv;
+    if (!getenv("MSD_PREFETCH")) m->prefetch = per_step > ((size_t)256 << 20);
+  }
   HIP_TRY(m, hipStreamSynchronize(s));
   m->finalized = true;
   return MSD_OK;
@@ -1519,7 +1532,7 @@ int msd_reset_graph(msd_model* m) {
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
   m->graph_batch = 0;
-  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps (unset: keep the choice of msd_finalize_weights)
   return MSD_OK;
 }
 
