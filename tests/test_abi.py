@@ -57,3 +57,12 @@ def test_product_never_imports_the_oracle():
       if f.endswith(('.py', '.h', '.hip', '.cpp')):
         src = open(os.path.join(dirpath, f)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_integration_stub_declares_the_same_struct():
+  """INTEGRATION.md shows the ctypes stub a reference maintainer would add: its MsdConfig must list the fields of
+  the header, in order (the stub is documentation, but a stale one would bind garbage)."""
+  text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+  body = text[text.index('class MsdConfig(ctypes.Structure):'):text.index('SCHEDULE = {')]
+  names = re.findall(r"'([a-z_0-9]+)'", body)
+  assert names == [n for n, _ in native.MsdConfig._fields_]
