@@ -100,6 +100,28 @@ def init_params(spec: config_lib.ModelSpec, seed: int = 0,
   return params
 
 
+def trained_like(params: Dict[str, np.ndarray], seed: int = 0, channel_sigma: float = 0.5,
+                 outlier_frac: float = 0.01, outlier_gain: float = 6.0, norm_sigma: float = 0.4) -> Dict[str, np.ndarray]:
+  """Reshape the dynamic range of initialiser weights towards what TRAINED transformers look like (no checkpoint
+  is reachable here): every kernel's output channels get log-normal gains exp(channel_sigma N(0,1)), a fraction
+  `outlier_frac` of them an extra `outlier_gain` (the few dominant feature channels of trained residual streams),
+  and the RMSNorm scales become log-normal around 1.  Parity tests use it to check that the split-bf16 arithmetic
+  is not tuned to the narrow range of fresh initialisers."""
+  rng = np.random.default_rng(seed)
+  out = {}
+  for name, v in params.items():
+    if name.endswith('/scale'):
+      v = (v * np.exp(norm_sigma * rng.standard_normal(v.shape))).astype(np.float32)
+    elif name.endswith('/kernel'):
+      gain = np.exp(channel_sigma * rng.standard_normal(v.shape[1]))
+      gain[rng.random(v.shape[1]) < outlier_frac] *= outlier_gain
+      # keep the layer's overall output power: trained layers are not 30 % louder than fresh ones on average
+      gain /= np.sqrt(np.mean(gain ** 2))
+      v = (v * gain[None, :]).astype(np.float32)
+    out[name] = np.ascontiguousarray(v, dtype=np.float32)
+  return out
+
+
 def segment_tokens(spec: config_lib.ModelSpec, segment: int, seed: int = 1234,
                    min_len: int = 128, max_len: int = 1536) -> np.ndarray:
   """int32 [1, inputs_length]: ``len ~ U{min..max}`` regular ids ``U{3..1390}``,

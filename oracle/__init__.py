@@ -10,7 +10,16 @@ Parity status (see DESIGN.md "Oracle"):
   * ``layers`` ops are PINNED against the reference's own known-answer tests
     (``layers_test.py``), restated in ``tests/test_oracle_kat.py``.
   * ``diffusion_utils`` / ``network`` / ``models`` have no reference tests and
-    JAX cannot be imported in this environment: for those the oracle is a
-    line-by-line restatement ("parity unpinned" by the reference; pinned only by
-    the mathematical identities in ``tests/test_oracle_identities.py``).
+    JAX cannot be imported in this environment.  They are PINNED against outputs of
+    the reference's OWN code: ``tests/golden/ref_shim.py`` installs a NumPy stand-in
+    for the slice of jax / flax.linen those files use and
+    ``tests/golden/make_ref_golden.py`` executes the reference's
+    ``predict_batch_with_aux`` (models.py -> network.py / layers.py /
+    diffusion_utils.py, imported from /root/reference) in float64 on seeded inputs;
+    ``tests/test_ref_golden.py`` holds the oracle to those fixtures at 1e-9 (whole
+    sampled segments, encodings, single decoder passes; every sampler / schedule /
+    model-output / cross-attention branch) and the parameter tree to the one the
+    reference's ``module.init`` creates.  What that does NOT pin: XLA's float32
+    rounding (the stand-in's arithmetic is NumPy) and jax.random (noise is an
+    input).
 """

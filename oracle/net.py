@@ -1,8 +1,10 @@
 """Oracle restatement of the reference ``models/diffusion/network.py``.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  No reference test covers
-this file ("parity unpinned" by the reference): it is a line-by-line
-restatement, inference path only (deterministic=True, dropout inactive).
+this file; it is a line-by-line restatement, inference path only
+(deterministic=True, dropout inactive), pinned at 1e-9 against the reference's
+own network.py executed over a NumPy stand-in of jax / flax
+(tests/golden/ref_*.npz, tests/test_ref_golden.py).
 
 Parameters are a flat dict ``name -> array`` using the Flax auto-naming the
 reference produces, e.g.

@@ -2,8 +2,10 @@
 ``predict_batch_with_aux``, ``audio_codecs.py`` feature scaling, and the
 per-song segment loop of ``beam/evaluation.py`` ``InferSong.process``.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); "parity unpinned" by the
-reference (no reference test touches these files).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  No reference test touches
+these files; ``predict_batch_with_aux`` is pinned at 1e-9 against the reference's
+own method executed over a NumPy stand-in of jax / flax
+(tests/golden/ref_*.npz, tests/test_ref_golden.py); the segment loop is not.
 """
 from __future__ import annotations
 

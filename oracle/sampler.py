@@ -2,8 +2,11 @@
 (evaluation path only).
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  No reference test covers
-this file ("parity unpinned" by the reference); it is a line-by-line
-restatement, pinned by the identities in tests/test_oracle_identities.py.
+this file; it is a line-by-line restatement, pinned by the identities in
+tests/test_oracle_identities.py and, through whole sampled segments of every
+branch (ddpm / ddim, eps / x0 / v, large / small / medium, cosine / linear, w = 1),
+against the reference's own diffusion_utils.eval_scan executed over a NumPy
+stand-in of jax (tests/golden/ref_*.npz, tests/test_ref_golden.py).
 
 RNG contract: the reference draws ``init_z = normal(rng)`` and per-step
 ``normal(fold_in(rng, i))`` from jax.random (threefry; jax version unpinned,

@@ -78,6 +78,31 @@ def song(preset, n_segments, name, weight_seed=0, seed=0, dtype='float64', threa
                         noise_seed=seed, n_segments=k + 1)
 
 
+def trained_like(dtype, threads=None):
+  """small / no-context, one 1000-step segment, weights reshaped by synthetic.trained_like (log-normal channel
+  gains, outlier channels, log-normal norm scales): float64 fixture + the float32 oracle's run as yardstick."""
+  spec = msd_amd.config.preset('small', num_steps=1000)
+  params = msd_amd.synthetic.trained_like(msd_amd.synthetic.init_params(spec, 0), seed=1)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend(dtype, threads=threads or os.cpu_count())
+  fm = fast.FastModel(xp, cfg, dc, params, False)
+  t, n = spec.task_feature_lengths['targets'], 128
+  batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, 0)}
+  init_z, noise = philox.segment_noise((1, t, n), 1000, seed=0, segment=0)
+  t0 = time.time()
+  out = xp.to_numpy(fm.predict(batch, init_z, noise)[0]).astype(np.float32)
+  print('trained_like %s: %.0fs' % (dtype, time.time() - t0), flush=True)
+  np.save(os.path.join(HERE, '_trained_like_%s.npy' % dtype), out)
+
+
+def trained_pack():
+  a = np.load(os.path.join(HERE, '_trained_like_float64.npy'))
+  b = np.load(os.path.join(HERE, '_trained_like_float32.npy'))
+  print('trained-like: float32 oracle vs float64 rms %.3e' % helpers.rms(b, a))
+  np.savez_compressed(os.path.join(HERE, 'small_trained_like_n1000.npz'), mel=a, rms_f32=helpers.rms(b, a),
+                      weight_seed=0, reshape_seed=1, noise_seed=0)
+
+
 def chainpack():
   """Merge the float64 chain and the float32 oracle's own chain into one fixture."""
   a = np.load(os.path.join(HERE, '_chain64.npz'))
@@ -108,3 +133,9 @@ if __name__ == '__main__':
     song('base_with_context', nseg, '_chain32.npz', dtype='float32', threads=nthr)
   if 'chainpack' in what:
     chainpack()
+  if 'trained64' in what:
+    trained_like('float64', nthr)
+  if 'trained32' in what:
+    trained_like('float32', nthr)
+  if 'trainedpack' in what:
+    trained_pack()

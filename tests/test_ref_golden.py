@@ -1,0 +1,117 @@
+"""tests/golden/ref_*.npz: outputs of the REFERENCE's own code (models.py predict_batch_with_aux over
+network.py / layers.py / diffusion_utils.py, executed in float64 over the NumPy stand-in of jax + flax:
+tests/golden/ref_shim.py, make_ref_golden.py).  They pin
+
+  CPU  the oracle (faithful restatement AND the shortcut FastModel) to the reference at 1e-9: whole
+       sampled segments, the encodings, single decoder passes; and the package's parameter tree to the
+       tree the reference's own `module.init` creates;
+  GPU  the HIP path to the reference directly: single decoder passes elementwise, sampled segments with
+       the float32 oracle as yardstick.
+
+Every reference-valid branch the package builds has a case: both models, both cross-attention styles,
+ragged / empty context, DDPM / DDIM, eps / x0 / v outputs, the three variance types, cosine / linear
+schedules, guidance on / off, and the full-size base_with_context and small shapes."""
+import os
+
+import numpy as np
+import pytest
+
+import msd_amd
+from tests import helpers, ref_cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = list(ref_cases.cases())
+TINY = [c for c in CASES if c.startswith('tiny')]
+FULL = [c for c in CASES if not c.startswith('tiny')]
+
+
+def _load(name):
+  g = np.load(os.path.join(GOLD, 'ref_%s.npz' % name))
+  spec, params, batch, init_z, noise = ref_cases.inputs(name)
+  assert ref_cases.digest(params, batch, init_z, noise) == str(g['digest']), \
+      'seeded inputs changed: regenerate with tests/golden/make_ref_golden.py'
+  return g, spec, params, batch, init_z, noise
+
+
+def _fast(spec, params, dtype):
+  from oracle import backend, fast
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend(dtype)
+  return xp, fast.FastModel(xp, cfg, dc, params, spec.has_context)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fast_oracle_reproduces_the_reference(name):
+  g, spec, params, batch, init_z, noise = _load(name)
+  xp, fm = _fast(spec, params, 'float64')
+  out = xp.to_numpy(fm.predict(batch, init_z, noise)[0])
+  assert np.abs(out - g['mel']).max() < 1e-9 * max(1.0, np.abs(g['mel']).max())
+  step = int(g['pass_step'])
+  for cond, key in ((True, 'pass_cond'), (False, 'pass_uncond')):
+    got = xp.to_numpy(fm.decoder_pass(xp.asarray(ref_cases.pass_z(init_z.shape)), step, cond))
+    assert np.abs(got - g[key]).max() < 1e-9 * np.abs(g[key]).max(), (name, key)
+
+
+@pytest.mark.parametrize('name', TINY)
+def test_faithful_oracle_reproduces_the_reference(name):
+  """oracle/predict.py + net.py + sampler.py: the line-by-line restatement, including the encodings
+  (padded positions kept, as the reference keeps them)."""
+  from oracle import backend, net, predict
+  g, spec, params, batch, init_z, noise = _load(name)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend('float64')
+  out, _ = predict.predict_batch_with_aux(xp, cfg, dc, params, batch, init_z, noise)
+  assert np.abs(xp.to_numpy(out) - g['mel']).max() < 1e-9 * np.abs(g['mel']).max()
+  if name not in ref_cases.WITH_ENCODINGS:
+    return
+  p = {k: xp.asarray(v) for k, v in params.items()}
+  if spec.has_context:
+    ctx = predict.MelGANCodec().scale_features(xp, xp.asarray(batch['encoder_continuous_inputs']), clip=True)
+    enc = net.context_transformer_encode(xp, cfg, p, batch['encoder_input_tokens'], ctx,
+                                         xp.asarray(batch['encoder_continuous_mask']))
+  else:
+    enc = net.transformer_encode(xp, cfg, p, batch['encoder_input_tokens'])
+  for i, (e, m) in enumerate(enc):
+    assert np.abs(xp.to_numpy(e) - g['enc%d' % i]).max() < 1e-10
+    np.testing.assert_array_equal(xp.to_numpy(m) > 0, g['mask%d' % i] > 0)
+
+
+@pytest.mark.parametrize('name', ['tiny_context_ddpm', 'tiny_ddpm', 'tiny_context_sum_cross', 'tiny_sum_cross',
+                                  'base_with_context_n3', 'small_n3'])
+def test_parameter_tree_is_the_one_the_reference_creates(name):
+  """Names and shapes of what the reference's `module.init` makes (stored in the fixture) == the package's
+  synthetic tree == what the checkpoint writer / reader round-trips; ABI weight names derive from it."""
+  g = np.load(os.path.join(GOLD, 'ref_%s.npz' % name))
+  spec = ref_cases.cases()[name][0]
+  mine = {k: str(tuple(v.shape)) for k, v in msd_amd.synthetic.init_params(spec, 0).items()}
+  theirs = dict(zip([str(n) for n in g['tree_names']], [str(s) for s in g['tree_shapes']]))
+  assert mine == theirs
+
+
+# ------------------------------------------------------------------------------------------------- device
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_device_against_the_reference(name):
+  import torch
+  g, spec, params, batch, init_z, noise = _load(name)
+  b = init_z.shape[0]
+  model = msd_amd.InferenceModel(params, spec, batch_size=b)
+  nm = model._get_native()
+  if spec.has_context:
+    nm.encode(b, batch['encoder_input_tokens'], torch.as_tensor(batch['encoder_continuous_inputs']).cuda(),
+              batch['encoder_continuous_mask'])
+  else:
+    nm.encode(b, batch['encoder_input_tokens'])
+  zd = torch.as_tensor(ref_cases.pass_z(init_z.shape).astype(np.float32)).cuda()
+  step = int(g['pass_step'])
+  for cond, key in ((True, 'pass_cond'), (False, 'pass_uncond')):
+    out = torch.zeros_like(zd)
+    nm.decoder_pass(b, step, zd, cond, out)
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - g[key]).max() / np.abs(g[key]).max()
+    print('%s %s: decoder pass vs reference, max rel err %.2e' % (name, key, err))
+    assert err < 2e-4, (name, key, err)
+  got, _ = model.predict(batch, init_z=init_z, noise=noise)
+  xp, fm = _fast(spec, params, 'float32')
+  ref32 = xp.to_numpy(fm.predict(batch, init_z, noise)[0])
+  helpers.assert_fp32_class(got, g['mel'].astype(np.float64), ref32, 'reference fixture ' + name)
