@@ -14,7 +14,8 @@ three cases) the encodings, one conditional and one unconditional decoder pass, 
 parameter tree (names + shapes) the reference's OWN `module.init` creates -- which the package's
 synthetic / checkpoint tree must equal.
 
-    python tests/golden/make_ref_golden.py [case ...]      # default: all cases
+    python tests/golden/make_ref_golden.py [--add-f32] [case ...]      # default: all cases
+    (--add-f32: only the float32 pass, added to existing files)
 """
 import os
 import sys
@@ -77,9 +78,11 @@ def reference_model(ref, spec):
   return ref.models.DiffusionModel(module=net.Transformer(config=cfg), diffusion_config=dc, audio_codec=codec)
 
 
-def run_case(ref, name):
+def predict(ref, name, wide):
+  """The reference's predict_batch_with_aux on the case's inputs; wide: float64, else float32 arrays."""
   import jax  # the stand-in
   spec, params, batch, init_z, noise = ref_cases.inputs(name)
+  ref_shim.WIDE = wide
   model = reference_model(ref, spec)
   tree = nest(params)
   b = {k: np.asarray(v, np.float64) if np.asarray(v).dtype.kind == 'f' else np.asarray(v) for k, v in batch.items()}
@@ -93,8 +96,29 @@ def run_case(ref, name):
     return noise[path[-1]]
   ref_shim.noise_provider = provider
   ref_shim.reset_accessed()
+  mel, _ = model.predict_batch_with_aux(tree, b, rng=root)
+  assert np.asarray(mel).dtype == (np.float64 if wide else np.float32)
+  return model, tree, b, root, np.asarray(mel)
+
+
+def add_f32(ref, name):
+  """Second pass: the same reference statements over float32 NumPy arrays (`mel_f32`): how far float32
+  arithmetic moves THIS case away from the float64 answer -- the yardstick of the device test."""
+  path = os.path.join(HERE, 'ref_%s.npz' % name)
+  g = dict(np.load(path))
   t0 = time.time()
-  mel, scores = model.predict_batch_with_aux(tree, b, rng=root)
+  g['mel_f32'] = predict(ref, name, wide=False)[4]
+  ref_shim.WIDE = True
+  np.savez_compressed(path, **g)
+  print('%-32s %6.1fs  float32 pass: rms vs float64 %.2e' % (
+      name, time.time() - t0, float(np.sqrt(np.mean((g['mel_f32'].astype(np.float64) - g['mel']) ** 2)))), flush=True)
+
+
+def run_case(ref, name):
+  import jax  # the stand-in
+  spec, params, batch, init_z, noise = ref_cases.inputs(name)
+  t0 = time.time()
+  model, tree, b, root, mel = predict(ref, name, wide=True)
   dt = time.time() - t0
   unused = sorted(set(params) - ref_shim.accessed)
   assert not unused, 'the reference never read %s' % unused
@@ -146,9 +170,13 @@ def run_case(ref, name):
 
 def main():
   ref = ref_shim.load_models()
-  names = sys.argv[1:] or list(ref_cases.cases())
+  args = sys.argv[1:]
+  only_f32 = '--add-f32' in args
+  names = [a for a in args if not a.startswith('--')] or list(ref_cases.cases())
   for n in names:
-    run_case(ref, n)
+    if not only_f32:
+      run_case(ref, n)
+    add_f32(ref, n)
 
 
 if __name__ == '__main__':

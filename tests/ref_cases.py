@@ -44,6 +44,8 @@ def cases():
       'tiny_context_linear': (_variant('tiny_context', 8, schedule=lin, train_schedule=dict(lin, num_steps=8)),
                               2, 'ragged', 8, 11, 19),
       'tiny_context_w1': (_variant('tiny_context', 4, cfg_weight=1.0), 2, 'ragged', 9, 12, 20),
+      # the full 1000-step chain on the tiny model (the bar of north_star applies: 1e-3 rms)
+      'tiny_context_n1000': (_variant('tiny_context', 1000), 1, 'ragged', 10, 15, 23),
       # full-size shapes (BASELINE configs 2 and 3), a few steps
       'base_with_context_n3': (_variant('base_with_context', 3), 1, 'ones', 0, 13, 21),
       'small_n3': (_variant('small', 3), 1, 'ones', 0, 14, 22),
