@@ -37,7 +37,9 @@ def _load(name):
 def _fast(spec, params, dtype):
   from oracle import backend, fast
   cfg, dc = helpers.oracle_configs(spec)
-  xp = backend.TorchBackend(dtype)
+  # one thread for the tiny model: its matrices are too small to split, and eight spinning OpenMP threads
+  # make a 1000-step run 100x slower on a busy box
+  xp = backend.TorchBackend(dtype, threads=1 if spec.t5.emb_dim <= 128 else None)
   return xp, fast.FastModel(xp, cfg, dc, params, spec.has_context)
 
 
@@ -60,7 +62,7 @@ def test_faithful_oracle_reproduces_the_reference(name):
   from oracle import backend, net, predict
   g, spec, params, batch, init_z, noise = _load(name)
   cfg, dc = helpers.oracle_configs(spec)
-  xp = backend.TorchBackend('float64')
+  xp = backend.TorchBackend('float64', threads=1)
   out, _ = predict.predict_batch_with_aux(xp, cfg, dc, params, batch, init_z, noise)
   assert np.abs(xp.to_numpy(out) - g['mel']).max() < 1e-9 * np.abs(g['mel']).max()
   if name not in ref_cases.WITH_ENCODINGS:
