@@ -124,7 +124,9 @@ def test_device_against_the_reference(name):
     torch.cuda.synchronize()
     err = np.abs(out.cpu().numpy() - g[key]).max() / np.abs(g[key]).max()
     print('%s %s: decoder pass vs reference, max rel err %.2e' % (name, key, err))
-    assert err < 2e-4, (name, key, err)
+    # max over every element; measured 4e-5 .. 7e-5 on the 2-layer tiny model, 0.9e-4 .. 1.7e-4 through the 8 / 12
+    # layers of small / base (profiles/r02k_gpu_tests.log); the reference's own float32 pass sits at 5e-5 (tiny)
+    assert err < (2e-4 if name.startswith('tiny') else 3e-4), (name, key, err)
   got, _ = model.predict(batch, init_z=init_z, noise=noise)
   # yardstick: the float32 oracle (torch): the reference's own float32 run (`mel_f32`) is printed beside it but
   # its OUTLIER count is luck (tiny_ddpm: one element flips at the clip of the first step, logsnr -20, and
