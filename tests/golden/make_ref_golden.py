@@ -147,18 +147,21 @@ def run_case(ref, name):
 
   # the tree the reference's own init creates (names + shapes; values are placeholders except the
   # sinusoidal tables of position_encoding='fixed', which are deterministic)
-  shapes = {k: tuple(v.shape) for k, v in flatten(module.init(
+  init_tree = flatten(module.init(
       root, **({'encoder_input_tokens': b['encoder_input_tokens'],
                 'encoder_continuous_inputs': b['encoder_continuous_inputs'],
                 'encoder_continuous_mask': b['encoder_continuous_mask']} if spec.has_context else
                {'encoder_input_tokens': b['encoder_input_tokens']}),
-      decoder_input_tokens=z, decoder_noise_time=tm, enable_dropout=False)['params']).items()}
+      decoder_input_tokens=z, decoder_noise_time=tm, enable_dropout=False)['params'])
+  shapes = {k: tuple(v.shape) for k, v in init_tree.items()}
   mine = {k: tuple(v.shape) for k, v in params.items()}
   assert shapes == mine, ('parameter trees differ', sorted(set(shapes.items()) ^ set(mine.items()))[:8])
 
   out = dict(mel=np.asarray(mel), pass_step=step, pass_cond=np.asarray(passes[1]),
              pass_uncond=np.asarray(passes[0]), digest=ref_cases.digest(params, batch, init_z, noise),
              tree_names=np.array(sorted(shapes)), tree_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+  if spec.t5.position_encoding == 'fixed':   # layers.sinusoidal() without permutation / offsets is deterministic
+    out['decoder_position_table'] = np.asarray(init_tree['decoder/Embed_0/embedding'])
   if name in ref_cases.WITH_ENCODINGS:   # random float64 does not compress: encodings for three cases only
     for i, (e, m) in enumerate(enc):
       out['enc%d' % i] = np.asarray(e)

@@ -13,8 +13,10 @@ from tests import helpers
 
 
 def _variant(preset, steps, cross=None, sampler=None, model_output=None, logvar=None, schedule=None,
-             train_schedule=None, cfg_weight=5.0, clip=True):
+             train_schedule=None, cfg_weight=5.0, clip=True, t5=None):
   spec = msd_amd.config.preset(preset, num_steps=steps, cfg_weight=cfg_weight)
+  if t5:
+    spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, **t5))
   if cross:
     spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style=cross))
   d = spec.diffusion
@@ -44,6 +46,9 @@ def cases():
       'tiny_context_linear': (_variant('tiny_context', 8, schedule=lin, train_schedule=dict(lin, num_steps=8)),
                               2, 'ragged', 8, 11, 19),
       'tiny_context_w1': (_variant('tiny_context', 4, cfg_weight=1.0), 2, 'ragged', 9, 12, 20),
+      'tiny_context_regular_positions': (_variant('tiny_context', 5, t5=dict(context_positions='regular',
+                                                                             position_encoding='fixed')),
+                                         2, 'ragged', 11, 16, 24),
       # the full 1000-step chain on the tiny model (the bar of north_star applies: 1e-3 rms)
       'tiny_context_n1000': (_variant('tiny_context', 1000), 1, 'ragged', 10, 15, 23),
       # full-size shapes (BASELINE configs 2 and 3), a few steps

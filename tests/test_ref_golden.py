@@ -152,3 +152,14 @@ def test_float32_oracle_is_in_the_class_of_the_references_float32_run(name):
   # a few huge steps) is luck in any float32 evaluation -- the reference's own float32 run of tiny_ddpm has one
   # flipped element at i = 5 that grows into 5 % outliers on that batch row, the float32 oracle 0.03 %
   assert np.median(mine) <= 3 * np.median(theirs) + 1e-6 and np.median(theirs) <= 3 * np.median(mine) + 1e-6
+
+
+def test_fixed_sinusoidal_table_equals_the_references_initialiser():
+  """position_encoding='fixed': layers.sinusoidal() (layers.py:50-107) is deterministic; the table the
+  reference's `module.init` creates (stored in the fixture) is what synthetic.init_params makes."""
+  name = 'tiny_context_regular_positions'
+  g = np.load(os.path.join(GOLD, 'ref_%s.npz' % name))
+  spec = ref_cases.cases()[name][0]
+  mine = msd_amd.synthetic.init_params(spec, 0)['decoder/Embed_0/embedding']
+  assert mine.shape == g['decoder_position_table'].shape
+  assert np.abs(mine - g['decoder_position_table']).max() < 1e-6
