@@ -162,4 +162,6 @@ def test_fixed_sinusoidal_table_equals_the_references_initialiser():
   spec = ref_cases.cases()[name][0]
   mine = msd_amd.synthetic.init_params(spec, 0)['decoder/Embed_0/embedding']
   assert mine.shape == g['decoder_position_table'].shape
-  assert np.abs(mine - g['decoder_position_table']).max() < 1e-6
+  # the fixture is float64; jax (and synthetic.py) round position * div_term to float32 before sin / cos:
+  # up to ulp(63) = 4e-6 of argument error
+  assert np.abs(mine - g['decoder_position_table']).max() < 1e-5
