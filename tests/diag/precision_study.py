@@ -56,10 +56,33 @@ def _fp8_round(xp, lo, kind):
   return q
 
 
+# fp16 planes instead of bf16 planes (same bytes, same MFMA rate: v_mfma_f32_16x16x32_f16): hi + lo carry 22
+# significand bits against 16.  Weights are pre-scaled per tensor by a power of two so that lo stays a NORMAL
+# fp16 number (|w| ~ 0.03: lo ~ 1e-5 would be subnormal); activations are split as they are, saturating.
+F16_VARIANTS = {
+    'f16x3': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16x3_noscale': dict(scale_w=False, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16x2_no_alo': dict(scale_w=True, mm=[(0, 0), (0, 1)]),      # activations single fp16 plane: 2 MFMAs per product
+    'f16x4': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0), (1, 1)]),
+}
+
+
+def _f16(x):
+  import torch
+  return x.clamp(-65504.0, 65504.0).to(torch.float16).to(x.dtype)
+
+
+def _split_f16(x):
+  hi = _f16(x)
+  return (hi, _f16(x - hi))
+
+
 class StudyModel(fast.FastModel):
   variant = 'x3'
 
   def _split(self, a, which='a'):
+    if self.variant in F16_VARIANTS:
+      return _split_f16(a)
     parts = super()._split(a)
     if self.variant in LO8_VARIANTS and len(parts) == 2:
       who, kind = LO8_VARIANTS[self.variant]
@@ -69,6 +92,16 @@ class StudyModel(fast.FastModel):
     return parts
 
   def _w(self, name):
+    if self.variant in F16_VARIANTS:
+      if name not in self._wcache:
+        import torch
+        w = self.p[name]
+        sc = 1.0
+        if F16_VARIANTS[self.variant]['scale_w']:
+          sc = float(2.0 ** torch.floor(torch.log2(16384.0 / w.abs().max())))   # max |w| lands in [8192, 16384)
+        hi, lo = _split_f16(w * sc)
+        self._wcache[name] = (hi, lo, sc)
+      return self._wcache[name]
     if name not in self._wcache:
       # weights [K, N]: the device stores W^T rows of K, so the scale runs along K = axis 0 here
       w = self.p[name]
@@ -81,6 +114,11 @@ class StudyModel(fast.FastModel):
     return self._wcache[name]
 
   def _mm_parts(self, a_parts, w_parts):
+    if self.variant in F16_VARIANTS:
+      y = 0
+      for a, b in F16_VARIANTS[self.variant]['mm']:
+        y = y + self.xp.matmul(a_parts[a], w_parts[b])
+      return y / w_parts[2]
     if self.variant not in MM_VARIANTS:
       return super()._mm_parts(a_parts, w_parts)
     y = 0
@@ -92,6 +130,8 @@ class StudyModel(fast.FastModel):
     xp = self.xp
     qk, pv = VARIANTS.get(self.variant, VARIANTS['x3'])
     def split(a):
+      if self.variant in F16_VARIANTS:
+        return _split_f16(a)
       hi = xp.round_bf16(a)
       return (hi, xp.round_bf16(a - hi))
     qs, ks, vs = split(q), split(k), split(v)
@@ -151,4 +191,4 @@ def main(names):
 
 
 if __name__ == '__main__':
-  main(sys.argv[1:] or list(VARIANTS) + list(MM_VARIANTS) + list(LO8_VARIANTS))
+  main(sys.argv[1:] or list(VARIANTS) + list(MM_VARIANTS) + list(LO8_VARIANTS) + list(F16_VARIANTS))
