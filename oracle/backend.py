@@ -122,6 +122,10 @@ class NumpyBackend:
     u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
     return u.view(np.float32).astype(self.dtype)
 
+  def round_f16(self, x):
+    """Round-to-nearest-even to IEEE half precision, saturating at +-65504, kept in self.dtype."""
+    return np.clip(np.asarray(x, np.float32), -65504.0, 65504.0).astype(np.float16).astype(self.dtype)
+
   # -- contractions ---------------------------------------------------------
   def matmul(self, a, b):
     return np.matmul(a, b)
@@ -227,3 +231,6 @@ class TorchBackend:
 
   def round_bf16(self, x):
     return x.to(self.t.bfloat16).to(self.dtype)
+
+  def round_f16(self, x):
+    return x.clamp(-65504.0, 65504.0).to(self.t.float16).to(self.dtype)

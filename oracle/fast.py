@@ -28,6 +28,9 @@ are proven against the faithful restatement (tests/test_oracle_fast.py):
             device 'bf16' mode
   'bf16x3'  operands split hi+lo bf16, three products (error ~2^-16) -- emulates
             the device 'bf16x3' mode
+  'f16x3'   the same with IEEE-half planes (22 significand bits; weights pre-scaled per
+            tensor by a power of two) -- the operand format planned for the device
+            (float32-class at the cost of bf16x3); 'f16' = one half plane
 """
 from __future__ import annotations
 
@@ -58,18 +61,30 @@ class FastModel:
     self._build_tables()
 
   # -- precision emulation ---------------------------------------------------
+  def _round16(self, a):
+    """One operand plane: bfloat16 (8 significand bits) or, for the 'f16*' modes, IEEE half (11 bits,
+    saturating at 65504 as the device conversion would)."""
+    return self.xp.round_f16(a) if self.precision.startswith('f16') else self.xp.round_bf16(a)
+
   def _split(self, a):
-    xp = self.xp
     if self.precision == 'f32':
       return (a,)
-    hi = xp.round_bf16(a)
-    if self.precision == 'bf16':
+    hi = self._round16(a)
+    if self.precision in ('bf16', 'f16'):
       return (hi,)
-    return (hi, xp.round_bf16(a - hi))
+    return (hi, self._round16(a - hi))
 
   def _w(self, name):
+    """Weight planes; fp16 planes are taken of the weight times a per-tensor power of two (largest
+    |w| lands in [8192, 16384)) so that the lo plane stays a normal half; `mm` undoes the scale on
+    the fp32 result, exactly."""
     if name not in self._wcache:
-      self._wcache[name] = self._split(self.p[name])
+      w = self.p[name]
+      sc = 1.0
+      if self.precision.startswith('f16'):
+        top = float(np.abs(self.xp.to_numpy(w)).max())
+        sc = 2.0 ** math.floor(math.log2(16384.0 / top)) if top > 0 else 1.0
+      self._wcache[name] = (self._split(w * sc) if sc != 1.0 else self._split(w), sc)
     return self._wcache[name]
 
   def _mm_parts(self, a_parts, w_parts):
@@ -81,15 +96,15 @@ class FastModel:
 
   def mm(self, a, name):
     """Device GEMM: operands in the emulated precision, fp32 accumulate."""
-    return self._mm_parts(self._split(a), self._w(name))
+    w_parts, sc = self._w(name)
+    y = self._mm_parts(self._split(a), w_parts)
+    return y if sc == 1.0 else y * (1.0 / sc)
 
   def rq(self, a):
-    """Storage rounding of a GEMM/attention output that the device keeps in bf16."""
-    if self.precision == 'f32':
-      return a
-    if self.precision == 'bf16':
-      return self.xp.round_bf16(a)
-    return a  # bf16x3 keeps hi+lo planes: ~fp32
+    """Storage rounding of a GEMM/attention output that the device keeps in ONE 16-bit plane."""
+    if self.precision in ('bf16', 'f16'):
+      return self._round16(a)
+    return a  # f32; the x3 modes keep hi+lo planes: ~fp32
 
   # -- S1: step-indexed tables (always full precision) -----------------------
   def _build_tables(self):

@@ -99,8 +99,7 @@ class StudyModel(fast.FastModel):
         sc = 1.0
         if F16_VARIANTS[self.variant]['scale_w']:
           sc = float(2.0 ** torch.floor(torch.log2(16384.0 / w.abs().max())))   # max |w| lands in [8192, 16384)
-        hi, lo = _split_f16(w * sc)
-        self._wcache[name] = (hi, lo, sc)
+        self._wcache[name] = (_split_f16(w * sc), sc)
       return self._wcache[name]
     if name not in self._wcache:
       # weights [K, N]: the device stores W^T rows of K, so the scale runs along K = axis 0 here
@@ -108,9 +107,9 @@ class StudyModel(fast.FastModel):
       if self.variant in LO8_VARIANTS and 'w' in LO8_VARIANTS[self.variant][0]:
         hi = self.xp.round_bf16(w)
         lo = _fp8_round(self.xp, (w - hi).T, LO8_VARIANTS[self.variant][1]).T
-        self._wcache[name] = (hi, lo)
+        self._wcache[name] = ((hi, lo), 1.0)
       else:
-        self._wcache[name] = fast.FastModel._split(self, w)
+        self._wcache[name] = (fast.FastModel._split(self, w), 1.0)
     return self._wcache[name]
 
   def _mm_parts(self, a_parts, w_parts):
@@ -118,7 +117,7 @@ class StudyModel(fast.FastModel):
       y = 0
       for a, b in F16_VARIANTS[self.variant]['mm']:
         y = y + self.xp.matmul(a_parts[a], w_parts[b])
-      return y / w_parts[2]
+      return y            # FastModel.mm undoes the weight scale
     if self.variant not in MM_VARIANTS:
       return super()._mm_parts(a_parts, w_parts)
     y = 0

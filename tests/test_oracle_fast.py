@@ -70,3 +70,36 @@ def test_numpy_bf16_rounding_matches_torch():
   xt = backend.TorchBackend('float32')
   b = xt.to_numpy(xt.round_bf16(xt.asarray(x)))
   np.testing.assert_array_equal(a, b)
+
+
+def test_numpy_f16_rounding_matches_torch_and_saturates():
+  rng = np.random.default_rng(1)
+  x = (rng.standard_normal(10000) * 10.0 ** rng.integers(-9, 7, 10000)).astype(np.float32)
+  a = backend.NumpyBackend('float32').round_f16(x)
+  xt = backend.TorchBackend('float32')
+  b = xt.to_numpy(xt.round_f16(xt.asarray(x)))
+  np.testing.assert_array_equal(a, b)
+  assert np.isfinite(a).all() and np.abs(a).max() == 65504.0
+
+
+def test_half_planes_beat_bfloat16_planes_on_a_decoder_pass():
+  """One decoder pass (no sampler in the way): operands as fp16 hi + lo (22 significand bits) are an order of
+  magnitude closer to float64 than as bf16 hi + lo (16 bits) -- the emulation behind DESIGN 3's fp16-plane plan."""
+  spec = msd_amd.config.preset('tiny_context', num_steps=10)
+  params = msd_amd.synthetic.init_params(spec, 2, norm_scale_jitter=0.1)
+  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
+  cfg, dc = helpers.oracle_configs(spec)
+  z = np.random.default_rng(0).standard_normal((2, 64, 128))
+  outs = {}
+  for prec, dtype in (('f32', 'float64'), ('f32', 'float32'), ('bf16x3', 'float32'), ('f16x3', 'float32')):
+    xp = backend.TorchBackend(dtype, threads=1)
+    fm = fast.FastModel(xp, cfg, dc, params, True, precision=prec)
+    fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+    outs[prec, dtype] = xp.to_numpy(fm.decoder_pass(xp.asarray(z), 4, True)).astype(np.float64)
+  # against the float32 run of the same statements: float32's own distance to float64 (4e-5 here) is the time
+  # embedding (sin / cos of arguments up to 2e4 in float32), shared by every float32-class mode
+  f32 = outs['f32', 'float32']
+  e32 = helpers.rms(f32, outs['f32', 'float64'])
+  eb, eh = helpers.rms(outs['bf16x3', 'float32'], f32), helpers.rms(outs['f16x3', 'float32'], f32)
+  print('decoder pass: float32 vs float64 %.2e | vs float32: bf16x3 %.2e  f16x3 %.2e' % (e32, eb, eh))
+  assert eh < 0.1 * eb
