@@ -27,7 +27,7 @@ value = frames of all ranks / max-over-ranks time; per-GPU work is K segments in
 The JSON line also carries
   roofline      dominant kernel class: algorithmic FLOP per launch / mean launch
                 duration measured with hipEvents on the launch stream
-                (msd_profile_steps), vs the dense bf16 MFMA peak;
+                (msd_profile_steps), vs the dense 16-bit MFMA peak (f16 = bf16 rate);
   cpu_baseline  the torch-CPU float32 oracle ("port") timed on a bounded sample
                 (encoders + a few DDPM steps, extrapolated linearly: per-step cost
                 is constant) on rank 0, N = 1 only.
@@ -46,14 +46,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparse 5 PF)
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md; not the 2:1-sparse 5 PF)
 PEAK_HBM_GBS = 8000.0
 
 
 def class_flops(spec, s_valid: float, passes: int):
   """Algorithmic FLOP per LAUNCH of each kernel class at batch 1:
   2MNK per GEMM, 2*H*T*S*d each for QK^T and PV; elementwise work ignored;
-  bf16x3 counts the product once (it is one fp32-class GEMM)."""
+  f16x3 counts the product once (it is one fp32-class GEMM)."""
   t5 = spec.t5
   d, h, f = t5.emb_dim, t5.num_heads, t5.mlp_dim
   j = h * t5.head_dim
@@ -75,7 +75,7 @@ def class_flops(spec, s_valid: float, passes: int):
 
 def class_bytes(spec, s_valid: float, passes: int, planes: int = 2):
   """ALGORITHMIC bytes per launch of each kernel class at batch 1: every operand read once, every
-  result written once (bf16 planes: 2 B x `planes`; fp32: 4 B).  What a launch must move if nothing
+  result written once (16-bit planes: 2 B x `planes`; fp32: 4 B).  What a launch must move if nothing
   were fetched twice -- the denominator of the waste ratio against the PMC fabric traffic."""
   t5 = spec.t5
   d, h, f = t5.emb_dim, t5.num_heads, t5.mlp_dim
@@ -100,10 +100,11 @@ def class_bytes(spec, s_valid: float, passes: int, planes: int = 2):
   }
 
 
-def library_hash():
+def library_hash(planes='f16'):
   """sha256 (first 16 hex) of the built HIP library: stamps which binary a profile was taken on."""
   import hashlib
-  path = os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'csrc', 'libmsd_amd.so')
+  path = os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'csrc',
+                      'libmsd_amd.so' if planes == 'f16' else 'libmsd_amd_bf16.so')
   if not os.path.exists(path):
     return None
   h = hashlib.sha256()
@@ -122,8 +123,8 @@ def profile_roofline(kernel_class, args):
   path = os.path.join(ROOT, 'profiles', 'roofline.json')
   if not os.path.exists(path):
     return None, 'profiles/roofline.json not present'
-  if args.preset != 'base_with_context' or args.batch != 1 or args.precision != 'bf16x3' or args.cfg_weight == 1.0:
-    return None, 'the profile was taken on base_with_context, B=1, bf16x3, CFG'
+  if args.preset != 'base_with_context' or args.batch != 1 or args.precision != 'f16x3' or args.cfg_weight == 1.0:
+    return None, 'the profile was taken on base_with_context, B=1, f16x3, CFG'
   with open(path) as f:
     t = json.load(f)
   cls = t.get('per_class', {}).get(kernel_class)
@@ -293,7 +294,9 @@ def main():
   ap.add_argument('--mode', choices=['replicas', 'chained', 'wavefront', 'masked'], default='replicas',
                   help='multi-GPU partitioning (module docstring); all modes equal replicas at --gpus 1')
   ap.add_argument('--preset', default='base_with_context')
-  ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+  ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'f16', 'bf16x3', 'bf16'],
+                  help="'f16x3' = hi + lo IEEE-half planes, 3 MFMAs per product (parity mode, libmsd_amd.so); 'bf16x3' = the "
+                       "same with bfloat16 planes (libmsd_amd_bf16.so); 'f16' / 'bf16' = one plane")
   ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
   ap.add_argument('--cfg-weight', type=float, default=5.0)
   ap.add_argument('--batch', type=int, default=1, help='independent songs synthesized together per GPU')
@@ -413,7 +416,7 @@ def main():
     with torch.cuda.device(model.device):
       prof = nm.profile_steps(nb, args.profile_steps, stream=model._stream.cuda_stream)
     flops = {k: v * nb for k, v in class_flops(spec, s_valid, passes).items()}
-    abytes = {k: v * nb for k, v in class_bytes(spec, s_valid, passes, 2 if args.precision == 'bf16x3' else 1).items()}
+    abytes = {k: v * nb for k, v in class_bytes(spec, s_valid, passes, 2 if args.precision.endswith('x3') else 1).items()}
     per_class = {}
     for name, (ms, launches) in prof.items():
       if launches:
@@ -464,8 +467,10 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/norm/softmax/sampler)'
-                 if args.precision == 'bf16x3' else 'bf16',
+        'dtype': {'f16x3': 'f16x3 (operands split into hi + lo half planes, 3 f16 MFMAs per product, fp32 accumulate; '
+                           'fp32 residual/norm/softmax/sampler)',
+                  'bf16x3': 'bf16x3 (operands split into hi + lo bfloat16 planes, 3 bf16 MFMAs per product, fp32 '
+                            'accumulate; fp32 residual/norm/softmax/sampler)'}.get(args.precision, args.precision),
         'data': ('synthetic (seeded tokens, reference-initialiser weights, Philox noise)' if args.data == 'tokens' else
                  'synthetic (seeded MIDI songs through the front end, reference-initialiser weights, Philox noise)'),
         'config': {'workload': '%s, %d-step DDPM, CFG w=%g, %d song(s) per GPU, %s, %d segments of %d frames per GPU'

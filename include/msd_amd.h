@@ -55,9 +55,13 @@ typedef enum msd_status {
  * statistics, softmax, FiLM, input/output projections and the sampler are always
  * fp32 (network.py:454; diffusion_utils.py:461). */
 typedef enum msd_precision {
-  MSD_PREC_BF16 = 0,   /* bf16 MFMA operands, fp32 accumulate                     */
-  MSD_PREC_BF16X3 = 1  /* operands split hi+lo bf16, 3 bf16 MFMAs per product:
-                          ~2^-16 relative error, fp32-class results (parity mode) */
+  MSD_PREC_F16 = 0,    /* one IEEE-half plane per operand (v_mfma_f32_*_f16), fp32 accumulate: fast, not parity-grade */
+  MSD_PREC_F16X3 = 1,  /* operands split hi + lo half planes (22 significand bits), 3 MFMAs per product
+                          (hi.hi + hi.lo + lo.hi): float32-class results -- the parity mode.  Conversions
+                          saturate at 65504; weights are packed times 2^9 and the accumulators rescaled. */
+  /* names of ABI <= 2 builds, whose planes were bfloat16 (same values, same meaning of "1 plane" / "hi + lo") */
+  MSD_PREC_BF16 = MSD_PREC_F16,
+  MSD_PREC_BF16X3 = MSD_PREC_F16X3
 } msd_precision;
 
 typedef enum msd_sampler_kind {

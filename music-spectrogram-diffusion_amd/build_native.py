@@ -1,8 +1,10 @@
-"""Build libmsd_amd.so (HIP/gfx950) in-tree with hipcc.
+"""Build the HIP/gfx950 libraries in-tree with hipcc.
 
 The shared library is the product's compute path; it is built next to the
 sources (music-spectrogram-diffusion_amd/csrc/libmsd_amd.so) so that it travels
-with the repository snapshot to the GPU box.  ``python -m`` cannot name this
+with the repository snapshot to the GPU box.  Two builds of the same sources:
+libmsd_amd.so (operand planes in IEEE half: precisions 'f16x3' / 'f16') and
+libmsd_amd_bf16.so (-DMSD_PLANE_BF16=1, bfloat16 planes: 'bf16x3' / 'bf16'; csrc/common.h).  ``python -m`` cannot name this
 package (dash), so run:  python music-spectrogram-diffusion_amd/build_native.py
 """
 from __future__ import annotations
@@ -15,6 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libmsd_amd.so')
+LIBS = {'f16': (LIB, []), 'bf16': (os.path.join(CSRC, 'libmsd_amd_bf16.so'), ['-DMSD_PLANE_BF16=1'])}
 SOURCES = ['msd_api.hip']
 HEADERS = ['common.h', 'chain.h', 'gemm_bf16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
            os.path.join('..', '..', 'include', 'msd_amd.h')]
@@ -27,10 +30,10 @@ def _hipcc():
   raise RuntimeError('hipcc not found (ROCm toolchain required to build the HIP library)')
 
 
-def needs_build() -> bool:
-  if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+  if not os.path.exists(lib):
     return True
-  t = os.path.getmtime(LIB)
+  t = os.path.getmtime(lib)
   for f in SOURCES + HEADERS + [os.path.join('..', 'build_native.py')]:
     if os.path.getmtime(os.path.join(CSRC, f)) > t:
       return True
@@ -38,14 +41,15 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-  if not force and not needs_build():
-    return LIB
-  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-fno-gpu-rdc', '-Wno-unused-result',
-         '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-  if verbose:
-    print('[build_native]', ' '.join(cmd), flush=True)
-  subprocess.run(cmd, check=True, cwd=CSRC)
+  """Builds both libraries (each only if older than its sources); returns the default one."""
+  for lib, defs in LIBS.values():
+    if not force and not needs_build(lib):
+      continue
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-fno-gpu-rdc', '-Wno-unused-result'] + defs + ['-o', lib] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+      print('[build_native]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
   return LIB
 
 

@@ -33,10 +33,10 @@
 namespace msd {
 
 struct AttnParams {
-  const bf16_t* q[2];   // [rows, ldq] row-major, head h at column h*64
-  const bf16_t* k[2];   // [seg][keys, ldk]
-  const bf16_t* vt[2];  // [seg][heads*64][vt_ld], key axis permuted per 16
-  bf16_t* o[2];         // [rows, ldo]
+  const h16_t* q[2];   // [rows, ldq] row-major, head h at column h*64
+  const h16_t* k[2];   // [seg][keys, ldk]
+  const h16_t* vt[2];  // [seg][heads*64][vt_ld], key axis permuted per 16
+  h16_t* o[2];         // [rows, ldo]
   const int* n_keys;    // [n_segs] valid keys per segment (device)
   int ldq, ldk, ldo, vt_ld;
   int q_rows_per_seg;   // query rows per segment (multiple of 64)
@@ -54,9 +54,9 @@ struct AttnParams {
   WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_bf16.h)
 };
 
-typedef __attribute__((ext_vector_type(8))) __bf16 frag8;
+typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
 
-__device__ __forceinline__ frag8 ld_frag(const bf16_t* p) {
+__device__ __forceinline__ frag8 ld_frag(const h16_t* p) {
   return as_frag(*reinterpret_cast<const uint4*>(p));
 }
 
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   const int vr = lane >> 4;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const bf16_t* kseg[NP];
-  const bf16_t* vseg[NP];
+  const h16_t* kseg[NP];
+  const h16_t* vseg[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
     kseg[pl] = p.k[pl] + (size_t)seg * p.k_seg_stride + head * 64 + kc * 8;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   frag8 qf[NP][4];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
-    const bf16_t* qp = p.q[pl] + qrow * p.ldq + head * 64 + hi * 8;
+    const h16_t* qp = p.q[pl] + qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[pl][s] = ld_frag(qp + s * 16);
   }
@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
         for (int pl = 0; pl < NP; ++pl)
           kf[pl] = *reinterpret_cast<const frag8*>(kt + pl * kAttKBytes + krow * 128 +
                                                    (((2 * sx + hi) ^ (krow & 7)) << 4));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][sx], s, 0, 0, 0);
+        s = MSD_MFMA_32X32X16(kf[0], qf[0][sx], s, 0, 0, 0);
         if (NP == 2) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[NP - 1][sx], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NP - 1], qf[0][sx], s, 0, 0, 0);
+          s = MSD_MFMA_32X32X16(kf[0], qf[NP - 1][sx], s, 0, 0, 0);
+          s = MSD_MFMA_32X32X16(kf[NP - 1], qf[0][sx], s, 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -240,14 +240,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
         uint32_t wh[4], wl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          bf16_t h0, l0, h1, l1;
+          h16_t h0, l0, h1, l1;
           if (NP == 2) {
-            split_bf16(pv[8 * ks + 2 * j], h0, l0);
-            split_bf16(pv[8 * ks + 2 * j + 1], h1, l1);
+            split_h16(pv[8 * ks + 2 * j], h0, l0);
+            split_h16(pv[8 * ks + 2 * j + 1], h1, l1);
             wl[j] = pack2(l0, l1);
           } else {
-            h0 = f2bf(pv[8 * ks + 2 * j]);
-            h1 = f2bf(pv[8 * ks + 2 * j + 1]);
+            h0 = f2h(pv[8 * ks + 2 * j]);
+            h1 = f2h(pv[8 * ks + 2 * j + 1]);
           }
           wh[j] = pack2(h0, h1);
         }
@@ -267,13 +267,13 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
             vf[pl][db] = *reinterpret_cast<const frag8*>(
                 vt + pl * kAttVBytes + d * 256 + (((kg * 4 + ks * 2 + hi) ^ (d & 15)) << 4));
           }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pf[0][ks], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], pf[0][ks], o1, 0, 0, 0);
+        o0 = MSD_MFMA_32X32X16(vf[0][0], pf[0][ks], o0, 0, 0, 0);
+        o1 = MSD_MFMA_32X32X16(vf[0][1], pf[0][ks], o1, 0, 0, 0);
         if (NP == 2) {
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pf[NP - 1][ks], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], pf[NP - 1][ks], o1, 0, 0, 0);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][0], pf[0][ks], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1][1], pf[0][ks], o1, 0, 0, 0);
+          o0 = MSD_MFMA_32X32X16(vf[0][0], pf[NP - 1][ks], o0, 0, 0, 0);
+          o1 = MSD_MFMA_32X32X16(vf[0][1], pf[NP - 1][ks], o1, 0, 0, 0);
+          o0 = MSD_MFMA_32X32X16(vf[NP - 1][0], pf[0][ks], o0, 0, 0, 0);
+          o1 = MSD_MFMA_32X32X16(vf[NP - 1][1], pf[0][ks], o1, 0, 0, 0);
         }
       }
     }
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
-      store_bf16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v);
+      store_h16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v);
     } else {
       const int heads = gridDim.x;
       float* po = p.part_o + (((size_t)ks * p.total_rows + row) * heads + head) * 64 + d0;
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
-  store_bf16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v);
+  store_h16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v);
 }
 
 template <int NP, int NS, int QB>

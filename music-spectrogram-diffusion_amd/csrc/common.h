@@ -1,33 +1,68 @@
-// Common device helpers for the gfx950 kernels (wave64, MFMA, bf16 split).
+// Common device helpers for the gfx950 kernels (wave64, MFMA, half-plane operand split).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace msd {
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits
-typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (8 bf16)
+typedef uint16_t h16_t;  // raw bits of one element of an operand plane (IEEE half, or bfloat16: see below)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 
 constexpr int kWave = 64;
 
-// round-to-nearest-even float -> bf16 bits.  The native cast lowers to
-// v_cvt_pk_bf16_f32 (two values per instruction); hand-written bit arithmetic costs
-// ~8 VALU ops per value and made the attention kernel VALU-bound.
-__device__ __forceinline__ bf16_t f2bf(float f) {
+// Operand planes: 16-bit elements, one plane (hi) or two (hi + lo) per GEMM / attention operand.
+//
+// Default build (libmsd_amd.so): IEEE half (v_mfma_f32_*_f16 -- the rate of the bf16 MFMAs).  hi + lo then carry 22
+// significand bits instead of bfloat16's 16, which puts the split-operand mode on the float32 oracle's error
+// (6.8e-5 against 1.4e-4 on the 1000-step segment; same bytes, same MFMA count).  Half has 5 exponent
+// bits, so
+//   * conversions saturate at +-65504 (v_cvt_f16_f32 alone would return inf); hi + lo covers |x| < 131008;
+//   * weights are packed multiplied by kWScale and every GEMM multiplies its fp32 accumulators by kWScaleInv (powers
+//     of two: exact), so that the lo plane of |w| ~ 0.03 weights is a NORMAL half (7e-6 would be subnormal: 2
+//     significant bits).  |w| < 128 is representable (checked at load time: msd_finalize_weights).
+// -DMSD_PLANE_BF16=1 (libmsd_amd_bf16.so): bfloat16 planes -- 8 exponent bits, no saturation, no weight scale, 16
+// significand bits in hi + lo: the range-safe alternative for weights / activations beyond the half range.
+#ifndef MSD_PLANE_BF16
+#define MSD_PLANE_BF16 0
+#endif
+
+#if MSD_PLANE_BF16
+typedef __bf16 plane_elem;
+#define MSD_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MSD_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+constexpr float kWScale = 1.0f, kWScaleInv = 1.0f, kPlaneMax = 3.0e38f;
+constexpr const char* kPlaneName = "bfloat16 planes";
+
+// round-to-nearest-even float -> bf16 bits.  The native cast lowers to v_cvt_pk_bf16_f32 (two values per
+// instruction); hand-written bit arithmetic costs ~8 VALU ops per value and made the attention kernel VALU-bound.
+__device__ __forceinline__ h16_t f2h(float f) {
   const __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(bf16_t, b);
+  return __builtin_bit_cast(h16_t, b);
 }
-__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ float h2f(h16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+#else
+typedef _Float16 plane_elem;
+#define MSD_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MSD_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+constexpr float kWScale = 512.0f, kWScaleInv = 1.0f / 512.0f, kPlaneMax = 65504.0f;
+constexpr const char* kPlaneName = "half planes";
 
-// hi/lo split: x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi)  (error ~2^-17 |x|)
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f2bf(x);
-  lo = f2bf(x - bf2f(hi));
+// round-to-nearest-even float -> half bits, saturating
+__device__ __forceinline__ h16_t f2h(float f) {
+  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+  return __builtin_bit_cast(h16_t, h);
+}
+__device__ __forceinline__ float h2f(h16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+#endif
+
+// hi/lo split: x ~= hi + lo with hi = plane(x), lo = plane(x - hi)
+__device__ __forceinline__ void split_h16(float x, h16_t& hi, h16_t& lo) {
+  hi = f2h(x);
+  lo = f2h(x - h2f(hi));
 }
 
-__device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) {
+__device__ __forceinline__ uint32_t pack2(h16_t a, h16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }
 

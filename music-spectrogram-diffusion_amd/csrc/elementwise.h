@@ -21,7 +21,7 @@ struct NormParams {
   const int* step_ptr;  // device scalar: current scan index i
   int film_slots, film_slot;
   int rows, D;
-  bf16_t* out[2];
+  h16_t* out[2];
   float* out_f32;
 };
 
@@ -63,11 +63,11 @@ __global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
       if (OUT == 2) {
         *reinterpret_cast<float4*>(p.out_f32 + off) = make_float4(y[0], y[1], y[2], y[3]);
       } else {
-        bf16_t h[4], l[4];
+        h16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (OUT == 1) split_bf16(y[e], h[e], l[e]);
-          else h[e] = f2bf(y[e]);
+          if (OUT == 1) split_h16(y[e], h[e], l[e]);
+          else h[e] = f2h(y[e]);
         }
         *reinterpret_cast<uint2*>(p.out[0] + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
         if (OUT == 1)
@@ -106,8 +106,8 @@ struct SamplerParams {
   float cond_wt;        // eval_condition_weight
   int clip_x0, ddim;
   int model_output = kOutEps;   // what the network predicts (diffusion_utils.py:288-322)
-  bf16_t* z_hi;         // optional bf16 planes of the new z (A operand of the next input projection)
-  bf16_t* z_lo;
+  h16_t* z_hi;         // optional bf16 planes of the new z (A operand of the next input projection)
+  h16_t* z_lo;
 };
 
 // model output -> (eps, x0) at the TRAIN schedule's log-SNR (diffusion_utils.py:288-322)
@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
     for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zin[k], e0[k], e1[k], nn[k]);
     *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
     if (p.z_hi) {
-      bf16_t h[4], l[4];
+      h16_t h[4], l[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) split_bf16(out[k], h[k], l[k]);
+      for (int k = 0; k < 4; ++k) split_h16(out[k], h[k], l[k]);
       *reinterpret_cast<uint2*>(p.z_hi + idx) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
       if (p.z_lo) *reinterpret_cast<uint2*>(p.z_lo + idx) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
     }
@@ -213,18 +213,25 @@ __global__ void scale_clip_kernel(const float* in, float* out, int n, float fmin
 // W^T bf16 planes [N_out_rows, K]; dst row r takes source column src_col[r]
 // (identity, QKV concatenation, or the 16-column wi_0/wi_1 interleave).
 // ---------------------------------------------------------------------------
-__global__ void pack_wt_kernel(const float* w, int K, int N, bf16_t* hi, bf16_t* lo,
-                               int dst_row0, int col_map_mode, int F) {
+__global__ void pack_wt_kernel(const float* w, int K, int N, h16_t* hi, h16_t* lo,
+                               int dst_row0, int col_map_mode, int F, unsigned* absmax) {
   // grid: (ceil(K/64), N) ; block 64: thread = k within chunk
   const int n = blockIdx.y;
   const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= K) return;
   int dst = dst_row0 + n;
   if (col_map_mode == 1) dst = dst_row0 + (n / 16) * 32 + (n % 16);        // wi_0 of the gated pair
   else if (col_map_mode == 2) dst = dst_row0 + (n / 16) * 32 + 16 + (n % 16);  // wi_1
-  const float v = w[(size_t)k * N + n];
-  bf16_t h, l;
-  split_bf16(v, h, l);
+  const float w0 = k < K ? w[(size_t)k * N + n] : 0.f;
+  if (absmax) {   // largest |w| seen (bits of a non-negative float order like unsigned ints): range check at load
+    float mx = fabsf(w0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (threadIdx.x == 0) atomicMax(absmax, __float_as_uint(mx));
+  }
+  if (k >= K) return;
+  const float v = w0 * kWScale;   // undone on the accumulators (gemm_tile)
+  h16_t h, l;
+  split_h16(v, h, l);
   hi[(size_t)dst * K + k] = h;
   if (lo) lo[(size_t)dst * K + k] = l;
 }
@@ -294,18 +301,18 @@ __global__ void philox_normal_kernel(float* out, int64_t n, uint32_t seed_lo, ui
 }
 
 // fp32 -> bf16 planes (test helper for the standalone ops)
-__global__ void split_planes_kernel(const float* in, bf16_t* hi, bf16_t* lo, int64_t n) {
+__global__ void split_planes_kernel(const float* in, h16_t* hi, h16_t* lo, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
-    bf16_t h, l;
-    split_bf16(in[i], h, l);
+    h16_t h, l;
+    split_h16(in[i], h, l);
     hi[i] = h;
     if (lo) lo[i] = l;
   }
 }
-__global__ void merge_planes_kernel(const bf16_t* hi, const bf16_t* lo, float* out, int64_t n) {
+__global__ void merge_planes_kernel(const h16_t* hi, const h16_t* lo, float* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = bf2f(hi[i]) + (lo ? bf2f(lo[i]) : 0.f);
+  if (i < n) out[i] = h2f(hi[i]) + (lo ? h2f(lo[i]) : 0.f);
 }
 
 }  // namespace msd

@@ -115,8 +115,8 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 }
 
 struct GemmParams {
-  const bf16_t* A[2];
-  const bf16_t* B[2];
+  const h16_t* A[2];
+  const h16_t* B[2];
   int lda, ldb;
   int M, N, K;
   WeightPrefetch pf;  // optional: warm a later launch's weights (see WeightPrefetch)
@@ -124,17 +124,17 @@ struct GemmParams {
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
 };
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(8))) plane_elem mfma_h16x8;
 // native vector (NOT HIP's uint4 struct): arrays of it stay in registers under SROA
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-__device__ __forceinline__ mfma_bf16x8 as_frag(uint4 v) {
-  union { uint4 u; mfma_bf16x8 f; } c;
+__device__ __forceinline__ mfma_h16x8 as_frag(uint4 v) {
+  union { uint4 u; mfma_h16x8 f; } c;
   c.u = v;
   return c.f;
 }
 
-__device__ __forceinline__ mfma_bf16x8 ld_frag16(const bf16_t* p) {
+__device__ __forceinline__ mfma_h16x8 ld_frag16(const h16_t* p) {
   return as_frag(*reinterpret_cast<const uint4*>(p));
 }
 
@@ -187,8 +187,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
   // B plane; lane (r = lane>>3, c' = lane&7) fetches global chunk c' ^ r of row 8i + r.
   const int r8 = lane >> 3, csrc = (lane & 7) ^ r8;
-  const bf16_t* ga[NP];
-  const bf16_t* gb[NP];
+  const h16_t* ga[NP];
+  const h16_t* gb[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
     ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8;
@@ -240,10 +240,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     const int c_ = (KK) * 4 + (lane >> 4);                                                   \
     _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                      \
       _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
-        FA[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(                                   \
+        FA[pl][i] = *reinterpret_cast<const mfma_h16x8*>(                                   \
             base_ + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c_));        \
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                         \
-        FB[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(                                   \
+        FB[pl][j] = *reinterpret_cast<const mfma_h16x8*>(                                   \
             base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c_)); \
     }                                                                                        \
   }
@@ -254,14 +254,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // last reads were issued), where it frees slot kt for the DMA of tile kt+NS and publishes
   // tile kt+1.  Before, every wave read a whole tile and then multiplied: LDS and MFMA pipes
   // alternated (64x96 tile: ~640 + ~580 clocks per K-tile) instead of overlapping.
-  mfma_bf16x8 fa0[NP][FM], fb0[NP][FN], fa1[NP][FM], fb1[NP][FN];
+  mfma_h16x8 fa0[NP][FM], fb0[NP][FN], fa1[NP][FM], fb1[NP][FN];
 #if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 2   // ablation (tools/ubench): no LDS fragment reads
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa0[pl][i] = fa1[pl][i] = mfma_bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+    for (int i = 0; i < FM; ++i) fa0[pl][i] = fa1[pl][i] = mfma_h16x8{1, 2, 3, 4, 5, 6, 7, 8};
 #pragma unroll
-    for (int j = 0; j < FN; ++j) fb0[pl][j] = fb1[pl][j] = mfma_bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+    for (int j = 0; j < FN; ++j) fb0[pl][j] = fb1[pl][j] = mfma_h16x8{1, 2, 3, 4, 5, 6, 7, 8};
   }
 #undef MSD_D_READ
 #define MSD_D_READ(FA, FB, BUF, KK) {}
@@ -296,10 +296,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     const char* base_ = smem + (BUF) * STAGE_BYTES;                                          \
     const int c_ = (KK) * 4 + (lane >> 4);                                                   \
     if (r_ < FM)                                                                             \
-      FA[pl_][r_ < FM ? r_ : 0] = *reinterpret_cast<const mfma_bf16x8*>(                     \
+      FA[pl_][r_ < FM ? r_ : 0] = *reinterpret_cast<const mfma_h16x8*>(                     \
           base_ + pl_ * A_BYTES + lds_tile_off(wm * WM + r_ * 16 + (lane & 15), c_));        \
     else                                                                                     \
-      FB[pl_][r_ < FM ? 0 : r_ - FM] = *reinterpret_cast<const mfma_bf16x8*>(                \
+      FB[pl_][r_ < FM ? 0 : r_ - FM] = *reinterpret_cast<const mfma_h16x8*>(                \
           base_ + NP * A_BYTES + pl_ * B_BYTES + lds_tile_off(wn * WN + (r_ - FM) * 16 + (lane & 15), c_)); \
   }
   // MFMA number E: products outermost, so one accumulator recurs every FM*FN MFMAs
@@ -307,7 +307,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   {                                                                                          \
     const int     pr_ = (E) / (FM * FN), t_ = (E) % (FM * FN), i_ = t_ / FN, j_ = t_ % FN;    \
     const int     pb_ = (pr_ == 1) ? NP - 1 : 0, pa_ = (pr_ == 2) ? NP - 1 : 0;              \
-    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[pb_][j_], FA[pa_][i_], acc[i_][j_], 0, 0, 0); \
+    acc[i_][j_] = MSD_MFMA_16X16X32(FB[pb_][j_], FA[pa_][i_], acc[i_][j_], 0, 0, 0); \
   }
 #if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 1   // ablation: no MFMA
 #undef MSD_D_MFMA1
@@ -397,7 +397,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #pragma unroll
     for (int j = 0; j < FN; ++j)
       *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
-          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          make_float4(acc[i][j][0] * kWScaleInv, acc[i][j][1] * kWScaleInv, acc[i][j][2] * kWScaleInv,
+                      acc[i][j][3] * kWScaleInv);   // weights are packed times kWScale (common.h)
   epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
   __syncthreads();
   epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true);
@@ -439,18 +440,18 @@ __device__ __forceinline__ void tile_row8(const float* s0, int m, int n, float v
 }
 
 template <int NP>
-__device__ __forceinline__ void store_bf16x8(bf16_t* const* planes, size_t off, const float v[8]) {
+__device__ __forceinline__ void store_h16x8(h16_t* const* planes, size_t off, const float v[8]) {
   uint32_t wh[4], wl[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    bf16_t h0, l0, h1, l1;
+    h16_t h0, l0, h1, l1;
     if (NP == 2) {
-      split_bf16(v[2 * e], h0, l0);
-      split_bf16(v[2 * e + 1], h1, l1);
+      split_h16(v[2 * e], h0, l0);
+      split_h16(v[2 * e + 1], h1, l1);
       wl[e] = pack2(l0, l1);
     } else {
-      h0 = f2bf(v[2 * e]);
-      h1 = f2bf(v[2 * e + 1]);
+      h0 = f2h(v[2 * e]);
+      h1 = f2h(v[2 * e + 1]);
     }
     wh[e] = pack2(h0, h1);
   }
@@ -567,7 +568,7 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
 // C (row-major bf16 planes) = acc [* rstd[m] + bias[n]]
 template <int NP>
 struct EpiStoreBf16 {
-  bf16_t* out[2];
+  h16_t* out[2];
   int ldc;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
@@ -592,7 +593,7 @@ struct EpiStoreBf16 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
       }
-      store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
     }
   }
 };
@@ -602,8 +603,8 @@ struct EpiStoreBf16 {
 // key axis permuted per 16 (seg = m / seg_len, key = m % seg_len).
 template <int NP>
 struct EpiQKV {
-  bf16_t* qk[2];
-  bf16_t* vt[2];
+  h16_t* qk[2];
+  h16_t* vt[2];
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
@@ -629,7 +630,7 @@ struct EpiQKV {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
         }
-        store_bf16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
+        store_h16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
       }
     } else {
       // transposed items: (column n, 8 consecutive rows = keys).  Keys o..o+7 of a
@@ -645,18 +646,18 @@ struct EpiQKV {
           for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[mm + e] + bn;
         }
         const int mg = m0 + mm, seg = mg / seg_len, key = mg % seg_len;
-        bf16_t* base[2];
+        h16_t* base[2];
         const size_t row = ((size_t)seg * vt_rows + (n0 + n - v_start)) * vt_ld + (key & ~15);
         base[0] = vt[0] + row;
         base[1] = vt[NP - 1] + row;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int kp = vt_perm16((key & 15) + 4 * hh);
-          bf16_t h[4], l[4];
+          h16_t h[4], l[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (NP == 2) split_bf16(v[4 * hh + e], h[e], l[e]);
-            else h[e] = f2bf(v[4 * hh + e]);
+            if (NP == 2) split_h16(v[4 * hh + e], h[e], l[e]);
+            else h[e] = f2h(v[4 * hh + e]);
           }
           *reinterpret_cast<uint2*>(base[0] + kp) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
           if (NP == 2)
@@ -699,7 +700,7 @@ template <int NP>
 struct EpiResidualNorm {
   float* x;
   int ldx;
-  bf16_t* y[2];
+  h16_t* y[2];
   float* ssq;
   int tiles;
   const float* g_lo; int g_lo_stride;
@@ -752,7 +753,7 @@ struct EpiResidualNorm {
         LG(lo_rows, n, col, g0, g1);
         v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
         v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
-        store_bf16x8<NP>(y, (size_t)row * ldx + col, v);
+        store_h16x8<NP>(y, (size_t)row * ldx + col, v);
       }
     };
     if (pre) {   // operands prefetched into the aux LDS region: explicit LDS pointers (ds_read)
@@ -791,7 +792,7 @@ struct EpiInProj {
   int ldx;
   const float* pos;
   int T, pass_rows, passes;
-  bf16_t* y[2];
+  h16_t* y[2];
   float* ssq;
   int tiles;
   const float* g; int g_stride;
@@ -835,7 +836,7 @@ struct EpiInProj {
         px[0] = make_float4(v[0], v[1], v[2], v[3]);
         px[1] = make_float4(v[4], v[5], v[6], v[7]);
         if ((item % (BN / 8)) == 0) ssq[r * tiles + n0 / BN] = sq;
-        store_bf16x8<NP>(y, r * ldx + col, w);
+        store_h16x8<NP>(y, r * ldx + col, w);
       }
     }
   }
@@ -881,7 +882,7 @@ struct EpiStoreF32 {
 //   g_out[m][n0/2 + j] = gelu(tile[m][pc(j)]) * tile[m][pc(j) + 16]
 template <int NP>
 struct EpiGeglu {
-  bf16_t* out[2];
+  h16_t* out[2];
   int ldc;  // = F
   RowScale rsc;  // bias table is indexed by PACKED column
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
@@ -915,7 +916,7 @@ struct EpiGeglu {
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
-      store_bf16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v);
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v);
     }
   }
 };

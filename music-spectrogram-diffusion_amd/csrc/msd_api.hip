@@ -37,7 +37,7 @@ const char* const kClassNames[KC_COUNT + 1] = {
     "in_proj_f32", "chain_mlp_qkv", nullptr};
 
 struct Planes {
-  bf16_t* p[2] = {nullptr, nullptr};
+  h16_t* p[2] = {nullptr, nullptr};
 };
 
 struct Weight {
@@ -162,6 +162,7 @@ struct msd_model {
   int cus = 0;                 // compute units of the device (chain grid = one block per CU)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
+  float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
   Profiler prof;
 };
@@ -483,7 +484,7 @@ void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const flo
 }
 
 template <int NP>
-void attention(Ctx& c, int kc, const Planes& q, int ldq, const bf16_t* const k[2], int ldk,
+void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
                int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr) {
@@ -521,7 +522,8 @@ int pack(msd_model* m, hipStream_t s, const float* w, int K, int N, Planes& dst,
          int mode) {
   dim3 grid((K + 63) / 64, N), block(64);
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w, K, N, dst.p[0],
-                     m->NP == 2 ? dst.p[1] : (bf16_t*)nullptr, dst_row0, mode, 0);
+                     m->NP == 2 ? dst.p[1] : (h16_t*)nullptr, dst_row0, mode, 0,
+                     reinterpret_cast<unsigned*>(m->d_absmax));
   HIP_TRY(m, hipGetLastError());
   return MSD_OK;
 }
@@ -742,7 +744,7 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     eq.vt[0] = m->evt.p[0]; eq.vt[1] = m->evt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = m->Lenc_pad; eq.vt_ld = m->Lenc_pad; eq.vt_rows = J;
     gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq, eq.v_start);
-    const bf16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
+    const h16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->Lenc_pad, m->evt, m->Lenc_pad, 0, m->eao, J,
                   m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
     gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
@@ -769,8 +771,8 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
     int Cv = 0;
     int nk[2] = {Lv, 0};
     Planes enc_tok = m->enc;  // rows [0, ...)
-    HIP_TRY(m, hipMemsetAsync(m->enc.p[0], 0, (size_t)m->S_pad * D * sizeof(bf16_t), s));
-    if (NP == 2) HIP_TRY(m, hipMemsetAsync(m->enc.p[1], 0, (size_t)m->S_pad * D * sizeof(bf16_t), s));
+    HIP_TRY(m, hipMemsetAsync(m->enc.p[0], 0, (size_t)m->S_pad * D * sizeof(h16_t), s));
+    if (NP == 2) HIP_TRY(m, hipMemsetAsync(m->enc.p[1], 0, (size_t)m->S_pad * D * sizeof(h16_t), s));
     if (Lv > 0) {
       const int rows = round_up(Lv, 64);
       HIP_TRY(m, hipMemcpyAsync(m->d_tokens, tokens_h + (size_t)b * L, L * sizeof(int), hipMemcpyHostToDevice, s));
@@ -832,7 +834,7 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
     if (m->n_cross == 1 && Sp > Sv) {
       for (int pl = 0; pl < NP; ++pl)
         HIP_TRY(m, hipMemsetAsync(m->enc.p[pl] + (size_t)Sv * D, 0,
-                                  (size_t)(m->S_pad - Sv) * D * sizeof(bf16_t), s));
+                                  (size_t)(m->S_pad - Sv) * D * sizeof(h16_t), s));
     }
     // S2: cross-attention K / V^T of every decoder layer, once per segment; one projection per key region
     // (concat_encodings: one region = both encodings, network.py:217-230; sum_cross_attends: a module and a
@@ -878,7 +880,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
     eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
     eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
     gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
-    const bf16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
+    const h16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
                   (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
     gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
@@ -888,7 +890,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
       gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross[0], D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
-      const bf16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
+      const h16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
       Planes vt;
       vt.p[0] = m->vtc.p[0] + loff;
       vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
@@ -970,7 +972,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       const WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
       gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
-    const bf16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
+    const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
       const WeightPrefetch pf = cond0 ? prefetch_of<NP>(m, w.wq_cross[0], J, D) : prefetch_of<NP>(m, w.mlp.wi, 2 * F, D);
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
@@ -1000,7 +1002,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       }
       for (int e = 0; e < m->n_cross; ++e) {
         const size_t r0 = (size_t)m->key_off[e];
-        const bf16_t* kc[2] = {m->kc.p[0] + loff + r0 * J, m->kc.p[NP - 1] + loff + r0 * J};
+        const h16_t* kc[2] = {m->kc.p[0] + loff + r0 * J, m->kc.p[NP - 1] + loff + r0 * J};
         Planes vt;
         vt.p[0] = m->vtc.p[0] + loff + r0;
         vt.p[1] = NP == 2 ? m->vtc.p[1] + loff + r0 : nullptr;
@@ -1098,7 +1100,7 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
 void split_z(msd_model* m, int64_t n, hipStream_t s) {
   if (!m->fold_norm) return;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, m->zp.p[0],
-                     m->NP == 2 ? m->zp.p[1] : (bf16_t*)nullptr, n);
+                     m->NP == 2 ? m->zp.p[1] : (h16_t*)nullptr, n);
 }
 
 template <int NP>
@@ -1153,7 +1155,10 @@ void set_func_attrs() {
 // =============================================================================
 extern "C" {
 
-const char* msd_version(void) { return "msd_amd 0.2.0 (gfx950, abi 2)"; }
+const char* msd_version(void) {
+  static const std::string v = std::string("msd_amd 0.3.0 (gfx950, abi 2, ") + kPlaneName + ")";
+  return v.c_str();
+}
 
 int msd_device_count(void) {
   int n = 0;
@@ -1261,6 +1266,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_step, 2));
   TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
   TRY(dalloc(m, &m->d_chain_err, 1));
+  TRY(dalloc(m, &m->d_absmax, 1));
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
   TRY(dalloc(m, &m->d_nkeys_cross, (size_t)2 * m->Bmax));
   m->h_nkeys_cross.assign((size_t)m->n_cross * m->Bmax, 0);
@@ -1391,7 +1397,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     // launch used to start on HBM-cold operands (1.172 -> 1.09 ms/step with the prefetch); the `small` preset moves
     // 143 MB, its weights simply stay cached from one step to the next and the touches are pure overhead
     // (489 -> 501 ms per segment: profiles/r02_prefetch_ab.log).  MSD_PREFETCH=0/1 overrides.
-    const size_t planes = (size_t)m->NP * sizeof(bf16_t);
+    const size_t planes = (size_t)m->NP * sizeof(h16_t);
     const size_t per_layer = ((size_t)3 * J * D + (size_t)D * J + (size_t)m->n_cross * 2 * ((size_t)J * D) +
                               (size_t)2 * m->F * D + (size_t)D * m->F) * planes;
     const size_t kv = (size_t)m->Ld * m->Bmax * m->S_pad * J * 2 * planes;
@@ -1399,6 +1405,15 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     if (!getenv("MSD_PREFETCH")) m->prefetch = per_step > ((size_t)256 << 20);
   }
   HIP_TRY(m, hipStreamSynchronize(s));
+  {  // half planes hold kWScale * w: |w| must stay below 65504 / kWScale (common.h)
+    float top = 0.f;
+    HIP_TRY(m, hipMemcpy(&top, m->d_absmax, sizeof(float), hipMemcpyDeviceToHost));
+    if (!(top < kPlaneMax / kWScale))
+      return fail(m, MSD_ERR_UNSUPPORTED,
+                  "a projection weight has magnitude %g: the %s of this build hold |w| < %g (the bfloat16-plane build, "
+                  "libmsd_amd_bf16.so / precision 'bf16x3', has no such limit)",
+                  (double)top, kPlaneName, (double)(kPlaneMax / kWScale));
+  }
   m->finalized = true;
   return MSD_OK;
 }
@@ -1596,7 +1611,7 @@ int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t ma
     float* tmp = nullptr;
     HIP_TRY(m, hipMalloc(&tmp, n * sizeof(float)));
     hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, pl->p[0],
-                       m->NP == 2 ? pl->p[1] : (const bf16_t*)nullptr, tmp, n);
+                       m->NP == 2 ? pl->p[1] : (const h16_t*)nullptr, tmp, n);
     hipError_t e = hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     HIP_TRY(m, e);
@@ -1663,7 +1678,7 @@ struct Scratch {
     return static_cast<Tp*>(q);
   }
 };
-void split(const float* in, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t s) {
+void split(const float* in, h16_t* hi, h16_t* lo, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, hi, lo, n);
 }
 }  // namespace
@@ -1677,14 +1692,14 @@ int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, floa
   Scratch sc;
   Planes a, w;
   for (int i = 0; i < NP; ++i) {
-    a.p[i] = sc.get<bf16_t>((size_t)M * K);
-    w.p[i] = sc.get<bf16_t>((size_t)N * K);
+    a.p[i] = sc.get<h16_t>((size_t)M * K);
+    w.p[i] = sc.get<h16_t>((size_t)N * K);
     if (!a.p[i] || !w.p[i]) return MSD_ERR_HIP;
   }
   split(a_dev, a.p[0], NP == 2 ? a.p[1] : nullptr, (int64_t)M * K, s);
   dim3 grid((K + 63) / 64, N), block(64);
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, w.p[0],
-                     NP == 2 ? w.p[1] : (bf16_t*)nullptr, 0, 0, 0);
+                     NP == 2 ? w.p[1] : (h16_t*)nullptr, 0, 0, 0, (unsigned*)nullptr);
   hipError_t e;
   if (NP == 2) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
   else e = launch_gemm_bf16_dma<1, 64, 64, 3>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
@@ -1715,10 +1730,10 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   int* d_nk = sc.get<int>(1);
   float* vt32 = sc.get<float>((size_t)J * n_keys);
   for (int i = 0; i < NP; ++i) {
-    q.p[i] = sc.get<bf16_t>((size_t)n_q * J);
-    k.p[i] = sc.get<bf16_t>((size_t)n_keys * J);
-    vt.p[i] = sc.get<bf16_t>((size_t)J * n_keys);
-    o.p[i] = sc.get<bf16_t>((size_t)n_q * J);
+    q.p[i] = sc.get<h16_t>((size_t)n_q * J);
+    k.p[i] = sc.get<h16_t>((size_t)n_keys * J);
+    vt.p[i] = sc.get<h16_t>((size_t)J * n_keys);
+    o.p[i] = sc.get<h16_t>((size_t)n_q * J);
     if (!q.p[i] || !k.p[i] || !vt.p[i] || !o.p[i]) return MSD_ERR_HIP;
   }
   if (!d_nk || !vt32) return MSD_ERR_HIP;
@@ -1754,7 +1769,7 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   hipError_t e = NP == 2 ? launch_attention<2>(p, heads, 1, s) : launch_attention<1>(p, heads, 1, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
-                     o.p[0], NP == 2 ? o.p[1] : (const bf16_t*)nullptr, o_dev, (int64_t)n_q * J);
+                     o.p[0], NP == 2 ? o.p[1] : (const h16_t*)nullptr, o_dev, (int64_t)n_q * J);
   return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
 }
 
@@ -1766,17 +1781,18 @@ namespace {
 bool pack_planes(Scratch& sc, const float* w_dev, int K, int N, int mode, int dst_row0, Planes* out, int rows,
                  hipStream_t s) {
   if (!out->p[0]) {
-    out->p[0] = sc.get<bf16_t>((size_t)rows * K);
-    out->p[1] = sc.get<bf16_t>((size_t)rows * K);
+    out->p[0] = sc.get<h16_t>((size_t)rows * K);
+    out->p[1] = sc.get<h16_t>((size_t)rows * K);
     if (!out->p[0] || !out->p[1]) return false;
   }
   dim3 grid((K + 63) / 64, N), block(64);
-  hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, out->p[0], out->p[1], dst_row0, mode, 0);
+  hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, out->p[0], out->p[1], dst_row0, mode, 0,
+                     (unsigned*)nullptr);
   return hipGetLastError() == hipSuccess;
 }
 bool split_new(Scratch& sc, const float* in, int64_t n, Planes* out, hipStream_t s) {
-  out->p[0] = sc.get<bf16_t>((size_t)n);
-  out->p[1] = sc.get<bf16_t>((size_t)n);
+  out->p[0] = sc.get<h16_t>((size_t)n);
+  out->p[1] = sc.get<h16_t>((size_t)n);
   if (!out->p[0] || !out->p[1]) return false;
   split(in, out->p[0], out->p[1], n, s);
   return true;
@@ -1844,7 +1860,7 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
   if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, w1_dev, K, D, 0, 0, &w1, D, s) ||
       !pack_planes(sc, w2_dev, D, N, 0, 0, &w2, N, s))
     return MSD_ERR_HIP;
-  y.p[0] = sc.get<bf16_t>((size_t)M * D); y.p[1] = sc.get<bf16_t>((size_t)M * D);
+  y.p[0] = sc.get<h16_t>((size_t)M * D); y.p[1] = sc.get<h16_t>((size_t)M * D);
   const int tiles = D / kNarrowTile;
   float* ssq = sc.get<float>((size_t)M * tiles);
   float* film = sc.get<float>((size_t)2 * D);   // one-step, one-slot table: scale | bias
@@ -1898,7 +1914,7 @@ int msd_op_geglu(const float* a_dev, const float* wi0_dev, const float* wi1_dev,
   if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wi0_dev, K, F, 1, 0, &wi, 2 * F, s) ||
       !pack_planes(sc, wi1_dev, K, F, 2, 0, &wi, 2 * F, s))
     return MSD_ERR_HIP;
-  g.p[0] = sc.get<bf16_t>((size_t)M * F); g.p[1] = sc.get<bf16_t>((size_t)M * F);
+  g.p[0] = sc.get<h16_t>((size_t)M * F); g.p[1] = sc.get<h16_t>((size_t)M * F);
   if (!g.p[0] || !g.p[1]) return MSD_ERR_HIP;
   EpiGeglu<2> eg;
   eg.out[0] = g.p[0]; eg.out[1] = g.p[1]; eg.ldc = F;
@@ -1921,8 +1937,8 @@ int msd_op_qkv(const float* a_dev, const float* wq_dev, const float* wk_dev, con
   if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wq_dev, K, J, 0, 0, &w, 3 * J, s) ||
       !pack_planes(sc, wk_dev, K, J, 0, J, &w, 3 * J, s) || !pack_planes(sc, wv_dev, K, J, 0, 2 * J, &w, 3 * J, s))
     return MSD_ERR_HIP;
-  qk.p[0] = sc.get<bf16_t>((size_t)M * 2 * J); qk.p[1] = sc.get<bf16_t>((size_t)M * 2 * J);
-  vt.p[0] = sc.get<bf16_t>((size_t)M * J); vt.p[1] = sc.get<bf16_t>((size_t)M * J);
+  qk.p[0] = sc.get<h16_t>((size_t)M * 2 * J); qk.p[1] = sc.get<h16_t>((size_t)M * 2 * J);
+  vt.p[0] = sc.get<h16_t>((size_t)M * J); vt.p[1] = sc.get<h16_t>((size_t)M * J);
   float* f32 = sc.get<float>((size_t)M * 2 * J);
   if (!qk.p[0] || !qk.p[1] || !vt.p[0] || !vt.p[1] || !f32) return MSD_ERR_HIP;
   EpiQKV<2> eq;
@@ -1973,7 +1989,7 @@ int msd_op_final_proj(const float* x_dev, const float* gamma_dev, const float* w
   float* wg = sc.get<float>((size_t)D * n);
   int* step = sc.get<int>(2);
   Planes za, zw;   // zero operands of the zero-update residual GEMM
-  for (int i = 0; i < 2; ++i) { za.p[i] = sc.get<bf16_t>((size_t)M * 64); zw.p[i] = sc.get<bf16_t>((size_t)D * 64); }
+  for (int i = 0; i < 2; ++i) { za.p[i] = sc.get<h16_t>((size_t)M * 64); zw.p[i] = sc.get<h16_t>((size_t)D * 64); }
   if (!x || !ssq || !wg || !step || !za.p[1] || !zw.p[1]) return MSD_ERR_HIP;
   if (hipMemcpyAsync(x, x_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return MSD_ERR_HIP;
   EpiResidualNorm<2> er;

@@ -182,13 +182,15 @@ class InferenceModel(object):
   """Wrapper of the HIP synthesizer with the reference's InferenceModel API."""
 
   def __init__(self, checkpoint_path, gin_config: Union[str, config_lib.ModelSpec],
-               batch_size: int = 1, precision: str = 'bf16x3', device: Optional[int] = None):
+               batch_size: int = 1, precision: str = 'f16x3', device: Optional[int] = None):
     """Args mirror inference.py:71-88.
 
     gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
       ``config.ModelSpec`` preset.
-    precision: 'bf16x3' (default; fp32-class results, meets the 1e-3 rms parity
-      bar) or 'bf16' (fastest; does NOT meet the bar).
+    precision: 'f16x3' (default; operands as hi + lo IEEE-half planes: float32-class
+      results, 5x inside the 1e-3 rms parity bar; weights must satisfy |w| < 128),
+      'bf16x3' (hi + lo bfloat16 planes: float32's exponent range, 2x the error; the
+      other library build), 'f16' / 'bf16' (one plane, fastest; do NOT meet the bar).
     device: HIP device index (default: torch's current device).
     """
     import torch  # device memory + streams only
@@ -264,7 +266,7 @@ class InferenceModel(object):
       with torch.cuda.device(self.device):
         params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
         cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision)
-        nm = native.NativeModel(cfg)
+        nm = native.NativeModel(cfg, planes=native.plane_format(self.precision))
         self._stream = torch.cuda.Stream(device=self.device)
         nm.load_weights(params, stream=self._stream.cuda_stream)
         self._params_np = params

@@ -20,14 +20,28 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libmsd_amd.so')
+LIB_PATHS = {'f16': LIB_PATH, 'bf16': os.path.join(_HERE, 'csrc', 'libmsd_amd_bf16.so')}
 
-MSD_PREC_BF16 = 0
-MSD_PREC_BF16X3 = 1
+MSD_PREC_F16 = 0      # one 16-bit plane per operand
+MSD_PREC_F16X3 = 1    # hi + lo planes, three MFMAs per product (the parity mode)
+MSD_PREC_BF16, MSD_PREC_BF16X3 = MSD_PREC_F16, MSD_PREC_F16X3
 MSD_SAMPLER_DDPM = 0
 MSD_SAMPLER_DDIM = 1
 MAX_KERNEL_CLASSES = 16
 
-PRECISIONS = {'bf16': MSD_PREC_BF16, 'bf16x3': MSD_PREC_BF16X3}
+# precision name -> (msd_precision value, plane format).  The plane format is a property of the LIBRARY build
+# (csrc/common.h): libmsd_amd.so holds operand planes in IEEE half -- 'f16x3' (hi + lo planes, 22 significand bits,
+# three MFMAs per product: the parity mode and the default) and 'f16' (one plane) --, libmsd_amd_bf16.so in
+# bfloat16 -- 'bf16x3' / 'bf16': 16 / 8 significand bits but float32's exponent range, for weights or activations
+# beyond the half range (|w| >= 128, |x| >= 131008).
+PRECISIONS = {'f16': MSD_PREC_F16, 'f16x3': MSD_PREC_F16X3, 'bf16': MSD_PREC_F16, 'bf16x3': MSD_PREC_F16X3}
+
+
+def plane_format(precision: str) -> str:
+  if precision not in PRECISIONS:
+    raise ValueError('precision must be one of %s' % sorted(PRECISIONS))
+  return 'bf16' if precision.startswith('bf16') else 'f16'
+
 
 # every symbol include/msd_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = (
@@ -66,14 +80,15 @@ class MsdConfig(ctypes.Structure):
       ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32)]
 
 
-_lib = None
+_libs = {}
 
 
-def load() -> ctypes.CDLL:
-  """dlopen libmsd_amd.so and declare prototypes.  Fails loudly if missing."""
-  global _lib
-  if _lib is not None:
-    return _lib
+def load(planes: str = 'f16') -> ctypes.CDLL:
+  """dlopen libmsd_amd.so (planes 'f16') or libmsd_amd_bf16.so ('bf16') and declare prototypes.  Fails loudly
+  if missing."""
+  if planes in _libs:
+    return _libs[planes]
+  LIB_PATH = LIB_PATHS[planes]
   if not os.path.exists(LIB_PATH):
     raise NativeLibraryError(
         'HIP library not built: %s is missing. Build it with '
@@ -120,7 +135,7 @@ def load() -> ctypes.CDLL:
     fn = getattr(lib, name)
     if name not in ('msd_version', 'msd_last_error', 'msd_destroy'):
       fn.restype = i32
-  _lib = lib
+  _libs[planes] = lib
   return lib
 
 
@@ -147,8 +162,9 @@ def _ptr(t) -> Optional[int]:
 class NativeModel:
   """Owns one ``msd_model*`` on the current HIP device."""
 
-  def __init__(self, cfg: MsdConfig):
-    self.lib = load()
+  def __init__(self, cfg: MsdConfig, planes: str = 'f16'):
+    self.lib = load(planes)
+    self.planes = planes
     self.cfg = cfg
     self.handle = ctypes.c_void_p()
     cfg.struct_size = ctypes.sizeof(MsdConfig)
@@ -271,7 +287,8 @@ def fill_normal(out, seed: int, stream_id: int, subseq: int, stream: int = 0):
 
 
 def op_gemm_bf16(precision: str, a, w, c, stream: int = 0):
-  lib = load()
+  """C = A.W with 16-bit operand planes in the format `precision` names (the symbol keeps its ABI-1 name)."""
+  lib = load(plane_format(precision))
   m, k = a.shape
   n = w.shape[1]
   rc = lib.msd_op_gemm_bf16(PRECISIONS[precision], _ptr(a), _ptr(w), _ptr(c), m, n, k, stream)
@@ -290,7 +307,7 @@ def op_gemm_f32(a, w, c, stream: int = 0):
 
 def op_attention(precision: str, q, k, v, o, heads: int, n_keys_valid: Optional[int] = None,
                  stream: int = 0):
-  lib = load()
+  lib = load(plane_format(precision))
   n_q, n_keys = q.shape[0], k.shape[0]
   nv = n_keys if n_keys_valid is None else n_keys_valid
   rc = lib.msd_op_attention(PRECISIONS[precision], _ptr(q), _ptr(k), _ptr(v), _ptr(o), n_q,

@@ -32,7 +32,17 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
   for name in _header_functions():
     assert hasattr(lib, name), name
-  assert b'gfx950' in lib.msd_version()
+  assert b'gfx950' in lib.msd_version() and b'half planes' in lib.msd_version()
+
+
+def test_bfloat16_plane_build_exports_the_same_abi(lib):
+  other = native.load('bf16')
+  for name in _header_functions():
+    assert hasattr(other, name), name
+  assert b'bfloat16 planes' in other.msd_version()
+  assert native.plane_format('f16x3') == 'f16' and native.plane_format('bf16x3') == 'bf16'
+  with pytest.raises(ValueError):
+    native.plane_format('fp8')
 
 
 def test_config_struct_layout_matches_header(lib):
@@ -44,10 +54,12 @@ def test_config_struct_layout_matches_header(lib):
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-  monkeypatch.setattr(native, '_lib', None)
-  monkeypatch.setattr(native, 'LIB_PATH', str(tmp_path / 'nope.so'))
+  monkeypatch.setattr(native, '_libs', {})
+  monkeypatch.setattr(native, 'LIB_PATHS', {'f16': str(tmp_path / 'nope.so'), 'bf16': str(tmp_path / 'nope2.so')})
   with pytest.raises(native.NativeLibraryError):
     native.load()
+  with pytest.raises(native.NativeLibraryError):
+    native.load('bf16')
 
 
 def test_product_never_imports_the_oracle():

@@ -39,13 +39,13 @@ def test_class_bytes_match_the_hand_count():
 def test_profile_roofline_lookup_and_staleness_stamp():
   """profiles/roofline.json (tools/make_roofline.py): per-class rocprof duration, MFMA utilisation and fabric
   bytes, stamped with the library hash; only for the configuration it was measured on."""
-  ok = argparse.Namespace(preset='base_with_context', batch=1, precision='bf16x3', cfg_weight=5.0)
+  ok = argparse.Namespace(preset='base_with_context', batch=1, precision='f16x3', cfg_weight=5.0)
   e, src = bench.profile_roofline('gemm_mlp_in_geglu', ok)
   assert e is not None and 'rocprofv3' in src
   assert 5.0 < e['avg_us'] < 40.0 and 0.0 < e['mfma_util'] < 1.0 and e['waste'] >= 1.0
   assert 10e6 < e['fabric_bytes_per_launch'] < 100e6
   assert isinstance(e['matches_binary'], bool) and 'profile_library_sha' in e
-  for other in (dict(preset='small'), dict(batch=8), dict(precision='bf16'), dict(cfg_weight=1.0)):
+  for other in (dict(preset='small'), dict(batch=8), dict(precision='f16'), dict(cfg_weight=1.0)):
     ns = argparse.Namespace(**{**vars(ok), **other})
     assert bench.profile_roofline('gemm_mlp_in_geglu', ns)[0] is None
   assert bench.profile_roofline('no_such_class', ok)[0] is None

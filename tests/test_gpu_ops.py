@@ -18,7 +18,7 @@ def _dev(torch, a):
   return torch.as_tensor(np.ascontiguousarray(a, np.float32)).cuda()
 
 
-@pytest.mark.parametrize('prec,tol', [('bf16', 2e-2), ('bf16x3', 2e-5)])
+@pytest.mark.parametrize('prec,tol', [('f16', 3e-3), ('f16x3', 1e-5), ('bf16', 2e-2), ('bf16x3', 2e-5)])
 @pytest.mark.parametrize('m,n,k', [(64, 64, 64), (256, 768, 768), (512, 128, 2048), (192, 320, 128)])
 def test_gemm_bf16(env, prec, tol, m, n, k):
   torch, native = env
@@ -36,10 +36,29 @@ def test_gemm_bf16_identity_detects_transposes(env):
   torch, native = env
   k = 128
   a = np.eye(k, dtype=np.float32)[:64] * 1.0
-  w = (np.arange(k * 192).reshape(k, 192) % 251).astype(np.float32)  # exactly representable in bf16
+  w = (np.arange(k * 192).reshape(k, 192) % 61).astype(np.float32)  # 512 w is exactly representable in one half plane
   c = torch.zeros((64, 192), dtype=torch.float32, device='cuda')
-  native.op_gemm_bf16('bf16', _dev(torch, a), _dev(torch, w), c)
+  native.op_gemm_bf16('f16', _dev(torch, a), _dev(torch, w), c)
   np.testing.assert_array_equal(c.cpu().numpy(), w[:64])
+
+
+@pytest.mark.parametrize('wscale,ascale,tol', [(1e-4, 1.0, 5e-4), (30.0, 1.0, 1e-5), (1.0, 300.0, 1e-5), (1.0, 1e-2, 5e-5)])
+def test_gemm_operand_magnitudes(env, wscale, ascale, tol):
+  """Half planes have 5 exponent bits: weights are packed times 2^9 (|w| < 128 representable) and the lo plane of
+  small operands becomes subnormal.  Weights 1e-4 x the initialiser scale keep ~18 significant bits (hi normal,
+  lo subnormal; the bound also covers an MFMA that flushed subnormal inputs: 2^-12); weights x30, activations
+  x300 and x0.01 stay float32-class."""
+  torch, native = env
+  rng = np.random.default_rng(17)
+  m, n, k = 128, 256, 768
+  a = (rng.standard_normal((m, k)) * ascale).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k) * wscale).astype(np.float32)
+  c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
+  native.op_gemm_bf16('f16x3', _dev(torch, a), _dev(torch, w), c)
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  err = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
+  print('gemm f16x3, weights x%g, activations x%g: max rel err %.2e' % (wscale, ascale, err))
+  assert err < tol, err
 
 
 @pytest.mark.parametrize('m,n,k', [(64, 64, 16), (1000, 128, 768), (256, 768, 128), (7, 64, 32)])
@@ -54,7 +73,7 @@ def test_gemm_f32(env, m, n, k):
   np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * np.abs(ref).max())
 
 
-@pytest.mark.parametrize('prec,tol', [('bf16', 3e-2), ('bf16x3', 3e-5)])
+@pytest.mark.parametrize('prec,tol', [('f16', 5e-3), ('f16x3', 2e-5), ('bf16', 3e-2), ('bf16x3', 3e-5)])
 @pytest.mark.parametrize('nq,nk,valid,heads', [(64, 32, 32, 1), (256, 256, 256, 2), (64, 2304, 2304, 3),
                                                (128, 512, 301, 2), (64, 64, 1, 1), (64, 64, 0, 2),
                                                (64, 160, 129, 1), (192, 1344, 1337, 2)])
@@ -92,7 +111,7 @@ def test_attention_spiked_key_forces_online_rescale(env):
   v = rng.standard_normal((nk, 64)).astype(np.float32)
   k[200] = q[3] * 40.0  # q[3].k[200] >> every other score, in the 7th key block
   o = torch.zeros((nq, 64), dtype=torch.float32, device='cuda')
-  native.op_attention('bf16x3', _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads)
+  native.op_attention('f16x3', _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads)
   xp = backend.NumpyBackend('float64')
   sh = lambda x, n: x.reshape(1, n, 1, 64).astype(np.float64)
   ref = ops.dot_product_attention(xp, sh(q, nq), sh(k, nk), sh(v, nk)).reshape(nq, 64)

@@ -13,10 +13,11 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
-def test_prefetch_destination_registers_are_never_rewritten(tmp_path):
+@pytest.mark.parametrize('defs', [[], ['-DMSD_PLANE_BF16=1']], ids=['half_planes', 'bfloat16_planes'])
+def test_prefetch_destination_registers_are_never_rewritten(tmp_path, defs):
   src = os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'csrc', 'msd_api.hip')
   listing = str(tmp_path / 'msd.s')
-  subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-o', listing, src],
+  subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S'] + defs + ['-o', listing, src],
                  check=True, cwd=os.path.dirname(src), capture_output=True)
   out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_prefetch_regs.py'), listing],
                        capture_output=True, text=True)

@@ -25,7 +25,8 @@ run_pass() {  # name, counters
   f=$(find /tmp/pmc_$1 -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python $ROOT/tools/pmc_summary.py $f > $OUT/${TAG}_pmc_$1.csv; else echo "no counters for $1"; tail -5 /tmp/pmc_$1.log; fi
 }
+if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la $OUT/${TAG}_*; exit 0; fi   # kernel trace only (short GPU budget)
 run_pass fetch "FETCH_SIZE"
 run_pass write "WRITE_SIZE"
-run_pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+run_pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
 ls -la $OUT/${TAG}_*

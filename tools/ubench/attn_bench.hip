@@ -11,7 +11,7 @@ double run(int segs, int heads, int nq, int nkeys, int kpad, int iters) {
   const int J = heads * 64;
   AttnParams p; int* nk; hipMalloc(&nk, segs * 4);
   std::vector<int> h(segs, nkeys); hipMemcpy(nk, h.data(), segs * 4, hipMemcpyHostToDevice);
-  bf16_t *q[2], *k[2], *v[2], *o[2];
+  h16_t *q[2], *k[2], *v[2], *o[2];
   for (int i = 0; i < 2; ++i) {
     hipMalloc(&q[i], (size_t)segs * nq * J * 2); hipMalloc(&k[i], (size_t)segs * kpad * J * 2);
     hipMalloc(&v[i], (size_t)segs * kpad * J * 2); hipMalloc(&o[i], (size_t)segs * nq * J * 2);

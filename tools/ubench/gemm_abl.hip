@@ -6,7 +6,7 @@
 using namespace msd;
 template <int NP, int BM, int BN, int NS>
 double run(int M, int N, int K, int iters) {
-  bf16_t *a[2], *b[2]; bf16_t* o[2];
+  h16_t *a[2], *b[2]; h16_t* o[2];
   for (int i = 0; i < 2; ++i) { hipMalloc(&a[i], (size_t)M * K * 2); hipMalloc(&b[i], (size_t)N * K * 2); hipMalloc(&o[i], (size_t)M * N * 2);
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)N * K * 2); }
   GemmParams p; for (int i = 0; i < 2; ++i) { p.A[i] = a[i]; p.B[i] = b[i]; } p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;

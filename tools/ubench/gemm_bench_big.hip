@@ -8,7 +8,7 @@ using namespace msd;
 
 template <int NP, int BM, int BN, int NS>
 double run(int M, int N, int K, int iters, bool resid) {
-  bf16_t *a[2], *b[2]; float* c; bf16_t* o[2];
+  h16_t *a[2], *b[2]; float* c; h16_t* o[2];
   for (int i = 0; i < 2; ++i) { hipMalloc(&a[i], (size_t)M * K * 2); hipMalloc(&b[i], (size_t)N * K * 2); hipMalloc(&o[i], (size_t)M * N * 2);
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)N * K * 2); }
   hipMalloc(&c, (size_t)M * N * 4); hipMemset(c, 0, (size_t)M * N * 4);

@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
 
   // global source of this thread: rows (tid>>3) + 32*i, 16-byte chunk tid&7
   const int ld_row = tid >> 3, ld_chunk = tid & 7;
-  const bf16_t* ga[NP];
-  const bf16_t* gb[NP];
+  const h16_t* ga[NP];
+  const h16_t* gb[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
     ga[pl] = p.A[pl] + (size_t)(m0 + ld_row) * p.lda + ld_chunk * 8;
@@ -84,15 +84,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
   {                                                                                        \
     const char* base_ = smem + (BUF) * STAGE_BYTES;                                        \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
-      mfma_bf16x8 fa[NP][FM], fb[NP][FN];                                                  \
+      mfma_h16x8 fa[NP][FM], fb[NP][FN];                                                  \
       const int c_ = kk * 4 + (lane >> 4);                                                 \
       if (MSD_ABL != 3 || kt == 0)                                                         \
       _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                  \
         _Pragma("unroll") for (int i = 0; i < FM; ++i)                                     \
-            fa[pl][i] = *reinterpret_cast<const mfma_bf16x8*>(                             \
+            fa[pl][i] = *reinterpret_cast<const mfma_h16x8*>(                             \
                 base_ + pl * A_BYTES + lds_tile_off(wm * WM + i * 16 + (lane & 15), c_));  \
         _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
-            fb[pl][j] = *reinterpret_cast<const mfma_bf16x8*>(                             \
+            fb[pl][j] = *reinterpret_cast<const mfma_h16x8*>(                             \
                 base_ + NP * A_BYTES + pl * B_BYTES + lds_tile_off(wn * WN + j * 16 + (lane & 15), c_)); \
       }                                                                                    \
       if (MSD_ABL == 2) {                                                                  \
@@ -103,10 +103,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
       } else                                                                               \
       _Pragma("unroll") for (int i = 0; i < FM; ++i)                                       \
       _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0); \
+        acc[i][j] = MSD_MFMA_16X16X32(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0); \
         if (NP == 2) {                                                                     \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NP - 1][j], fa[0][i], acc[i][j], 0, 0, 0); \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[NP - 1][i], acc[i][j], 0, 0, 0); \
+          acc[i][j] = MSD_MFMA_16X16X32(fb[NP - 1][j], fa[0][i], acc[i][j], 0, 0, 0); \
+          acc[i][j] = MSD_MFMA_16X16X32(fb[0][j], fa[NP - 1][i], acc[i][j], 0, 0, 0); \
         }                                                                                  \
       }                                                                                    \
     }                                                                                      \

@@ -10,7 +10,7 @@ using namespace msd;
 template <class T> T* dmalloc(size_t n, int fill = 0) { T* p; (void)hipMalloc(&p, n * sizeof(T)); (void)hipMemset(p, fill, n * sizeof(T)); return p; }
 
 template <int BM, int BN, int NS, class Epi>
-double timeit(GemmParams p, Epi epi, bf16_t* b0, bf16_t* b1, size_t bstride, int copies, int iters) {
+double timeit(GemmParams p, Epi epi, h16_t* b0, h16_t* b1, size_t bstride, int copies, int iters) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto go = [&](int it) { p.B[0] = b0 + (size_t)(it % copies) * bstride; p.B[1] = b1 + (size_t)(it % copies) * bstride;
                           (void)launch_gemm_bf16_dma<2, BM, BN, NS>(p, epi, 0); };
@@ -29,8 +29,8 @@ int main() {
   float* g = dmalloc<float>((size_t)D, 0x3c);
   float* x = dmalloc<float>((size_t)M * D);
   RowScale rs; rs.ssq = ssq; rs.tiles = tiles; rs.inv_d = 1.0f / D; rs.bias = bias; rs.bias_step_stride = 0; rs.step_ptr = step;
-  auto planes = [&](size_t n, bf16_t** p) { p[0] = dmalloc<bf16_t>(n, 0x3c); p[1] = dmalloc<bf16_t>(n, 0x3b); };
-  bf16_t *y[2], *gact[2], *qk[2], *vt[2], *gout[2], *wq[2], *wi[2], *wo[2];
+  auto planes = [&](size_t n, h16_t** p) { p[0] = dmalloc<h16_t>(n, 0x3c); p[1] = dmalloc<h16_t>(n, 0x3b); };
+  h16_t *y[2], *gact[2], *qk[2], *vt[2], *gout[2], *wq[2], *wi[2], *wo[2];
   planes((size_t)M * D, y); planes((size_t)M * F, gact); planes((size_t)M * 2 * J + 4096, qk); planes((size_t)M * J + 4096, vt); planes((size_t)M * 2 * F + 4096, gout);
   planes((size_t)COPIES * 3 * J * D, wq); planes((size_t)COPIES * 2 * F * D, wi); planes((size_t)COPIES * D * F, wo);
   GemmParams p; p.A[0] = y[0]; p.A[1] = y[1]; p.lda = D; p.ldb = D; p.M = M; p.K = D;

@@ -18,7 +18,7 @@ double run_cold(int M, int N, int K, int iters) {
   const size_t wbytes = (size_t)N * K * 2;
   int COPIES = (int)((600ull << 20) / (2 * wbytes)) + 1;
   if (COPIES > 64) COPIES = 64;
-  bf16_t *a[2], *b[2], *o[2];
+  h16_t *a[2], *b[2], *o[2];
   for (int i = 0; i < 2; ++i) {
     hipMalloc(&a[i], (size_t)M * K * 2); hipMalloc(&b[i], (size_t)COPIES * wbytes); hipMalloc(&o[i], (size_t)M * N * 2);
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)COPIES * wbytes);
