@@ -205,13 +205,13 @@ def test_geglu_vs_oracle(env, m, k, f):
   assert err < 3e-5
   # column identity: a distinct wi_1 column per output catches any mix-up of the 16-column interleave
   wi1b = np.zeros((k, f), np.float32)
-  wi1b[0, :] = np.arange(1, f + 1)
+  wi1b[0, :] = np.arange(1, f + 1) / 32.0   # < 128: inside the weight range of the half-plane build (common.h)
   a1 = np.zeros((m, k), np.float32)
   a1[:, 0] = 1.0
   wi0b = np.zeros((k, f), np.float32)
   wi0b[0, :] = 30.0   # gelu(30) == 30 in float32
   native.op_geglu(_dev(torch, a1), _dev(torch, wi0b), _dev(torch, wi1b), out)
-  np.testing.assert_allclose(out.cpu().numpy()[0], 30.0 * np.arange(1, f + 1), rtol=1e-5)
+  np.testing.assert_allclose(out.cpu().numpy()[0], 30.0 * np.arange(1, f + 1) / 32.0, rtol=1e-5)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -51,6 +51,9 @@ def main():
   tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
   s_valid = float(sys.argv[2]) if len(sys.argv) > 2 else 1100.0 + 256.0
   prof = os.path.join(ROOT, 'profiles')
+  # PMC_TAG=<other tag>: take the counter passes of another round (same launches, same bytes) when a round had
+  # GPU time for the kernel trace only; the result says so in 'source'
+  pmc_tag = os.environ.get('PMC_TAG', tag)
   spec = msd_amd.config.preset('base_with_context')
   flops = bench.class_flops(spec, s_valid, 2)
   abytes = bench.class_bytes(spec, s_valid, 2)
@@ -75,7 +78,7 @@ def main():
     e['kernel'] = ' | '.join(e['kernel'])
 
   def pmc(name):
-    path = os.path.join(prof, '%s_pmc_%s.csv' % (tag, name))
+    path = os.path.join(prof, '%s_pmc_%s.csv' % (pmc_tag, name))
     if not os.path.exists(path):
       return {}
     acc = {}
@@ -118,7 +121,11 @@ def main():
   doc = {
       'tag': tag, 'library_sha': sha,
       'source': 'rocprofv3 --kernel-trace --stats and separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group) over '
-                'bench.py, base_with_context B=1 bf16x3 CFG (tools/profile_round.sh %s); profiles/%s_*.csv' % (tag, tag),
+                'bench.py, base_with_context B=1 %s CFG (tools/profile_round.sh %s); profiles/%s_*.csv' % (
+                    'f16x3', tag, tag) + ('' if pmc_tag == tag else
+                '; COUNTER passes (MFMA busy cycles, FETCH_SIZE, WRITE_SIZE) from profiles/%s_pmc_*.csv, taken on the '
+                'bfloat16-plane binary of the same kernels: same launches, same operand bytes, same MFMA count -- '
+                'mfma_util and fabric GB/s are those counts over THIS trace\'s durations' % pmc_tag),
       'assumptions': {'clock_ghz': CLOCK_GHZ, 'simds': SIMDS, 'peak_bf16_tflops': bench.PEAK_BF16_TFLOPS,
                       's_valid_keys': s_valid,
                       'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 16 B/lane reads at half size); WRITE_SIZE as reported'},

@@ -28,5 +28,5 @@ run_pass() {  # name, counters
 if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la $OUT/${TAG}_*; exit 0; fi   # kernel trace only (short GPU budget)
 run_pass fetch "FETCH_SIZE"
 run_pass write "WRITE_SIZE"
-run_pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+run_pass sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
 ls -la $OUT/${TAG}_*
