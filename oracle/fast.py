@@ -28,9 +28,9 @@ are proven against the faithful restatement (tests/test_oracle_fast.py):
             device 'bf16' mode
   'bf16x3'  operands split hi+lo bf16, three products (error ~2^-16) -- emulates
             the device 'bf16x3' mode
-  'f16x3'   the same with IEEE-half planes (22 significand bits; weights pre-scaled per
-            tensor by a power of two) -- the operand format planned for the device
-            (float32-class at the cost of bf16x3); 'f16' = one half plane
+  'f16x3'   the same with IEEE-half planes (22 significand bits; weights pre-scaled by a
+            power of two) -- emulates the device 'f16x3' mode, the default (DESIGN.md 3:
+            float32-class at the cost of bf16x3); 'f16' = one half plane
 """
 from __future__ import annotations
 

@@ -103,12 +103,11 @@ def test_base_with_context_chain_depth():
   """Chain depth (beam/evaluation.py:191-223): segment k+1 is conditioned on the DEVICE's own segment k; the
   bench chains 20 segments, a 10-minute song 118.  Fixture: the float64 oracle's free-running 12-segment song
   plus the float32 oracle's OWN free-running song (`rms_f32`: how far the reference's arithmetic drifts from
-  float64 at each depth).  Measured (MI355X, profiles/r02k_chain12.log): both drifts GROW along the chain -- the
-  float32 oracle's from 0.6e-4 to 4.9e-4, the device's from 1.7e-4 to 2.5e-3, a steady 3x .. 8x above it -- so a
-  free-running device song leaves north_star's 1e-3 bar at depth 6 (float32 arithmetic would at about depth 20).
-  Asserted: inside 1e-3 for the first six segments; never more than 10x the float32 oracle's own drift (the
-  trajectories diverge at the rate float32-class arithmetic does, no faster); the per-segment bar at ANY depth
-  is the teacher-forced test below."""
+  float64 at each depth: 0.6e-4 -> 4.9e-4, roughly linear -- a free-running song is a feedback loop).
+  Measured (MI355X): with the half operand planes (default) the device is ON the float32 oracle's drift, x0.9 ..
+  x1.1 at every depth, 0.63e-4 -> 5.3e-4 (profiles/r02m_gpu_tests.log); with the bfloat16 planes of the other
+  build it runs 3x .. 8x above it and leaves 1e-3 at depth 6 (profiles/r02k_chain12.log).
+  Asserted: north_star's 1e-3 at every depth, and never more than twice the float32 oracle's own drift."""
   g = np.load(os.path.join(GOLD, 'base_chain_n1000.npz'))
   n_seg, t = int(g['n_segments']), 256
   assert n_seg >= 12
@@ -117,7 +116,7 @@ def test_base_with_context_chain_depth():
   for k in range(n_seg):
     e = helpers.rms(got[:, k * t:(k + 1) * t], g['mel'][:, k * t:(k + 1) * t])
     f = float(g['rms_f32'][k])
-    bar = min(1e-3, 10 * f) if k < 6 else 10 * f
+    bar = min(1e-3, 2 * f)
     rows.append('segment %2d: device %.3e | float32 oracle %.3e | x%.1f | bar %.1e %s'
                 % (k, e, f, e / f, bar, 'ok' if e <= bar else 'FAIL'))
     ok = ok and e <= bar
@@ -128,7 +127,8 @@ def test_base_with_context_chain_depth():
 @pytest.mark.gpu
 def test_base_with_context_every_segment_on_the_reference_context():
   """The same 12 segments with the context the float64 fixture holds (segment k conditioned on the FIXTURE's
-  segment k-1): identical inputs, so north_star's bar applies at every depth -- rms <= 1e-3 per segment."""
+  segment k-1): identical inputs, so north_star's bar applies at every depth -- rms <= 1e-3 per segment
+  (measured 0.57e-4 .. 0.87e-4 with half planes, 1.5e-4 .. 2.2e-4 with bfloat16 planes)."""
   g = np.load(os.path.join(GOLD, 'base_chain_n1000.npz'))
   n_seg, t = int(g['n_segments']), 256
   _, got = _song('base_with_context', n_seg, int(g['noise_seed']), teacher=g['mel'].astype(np.float32))
