@@ -447,7 +447,7 @@ def main():
         'algorithmic_gflop_per_launch': round(flops[dom] / 1e9, 4),
         'algorithmic_bytes_per_launch': int(abytes.get(dom, 0)),
         'profile': prof_entry, 'profile_source': prof_src,
-        'library_sha': library_hash(),
+        'library_sha': library_hash('bf16' if args.precision.startswith('bf16') else 'f16'),
         'whole_step': {
             'algorithmic_gflop': round(step_flops / 1e9, 2),
             'eager_ms': round(sum(v['ms_per_step'] for v in per_class.values()), 4),
