@@ -28,8 +28,8 @@ are proven against the faithful restatement (tests/test_oracle_fast.py):
             device 'bf16' mode
   'bf16x3'  operands split hi+lo bf16, three products (error ~2^-16) -- emulates
             the device 'bf16x3' mode
-  'f16x3'   the same with IEEE-half planes (22 significand bits; weights pre-scaled by a
-            power of two) -- emulates the device 'f16x3' mode, the default (DESIGN.md 3:
+  'f16x3'   the same with IEEE-half planes (22 significand bits; weights times 2^9, as the
+            device packs them) -- emulates the device 'f16x3' mode, the default (DESIGN.md 3:
             float32-class at the cost of bf16x3); 'f16' = one half plane
 """
 from __future__ import annotations
@@ -74,16 +74,15 @@ class FastModel:
       return (hi,)
     return (hi, self._round16(a - hi))
 
+  W_SCALE_F16 = 512.0   # csrc/common.h kWScale: half-plane weights are packed times 2^9
+
   def _w(self, name):
-    """Weight planes; fp16 planes are taken of the weight times a per-tensor power of two (largest
-    |w| lands in [8192, 16384)) so that the lo plane stays a normal half; `mm` undoes the scale on
-    the fp32 result, exactly."""
+    """Weight planes; half planes are taken of the weight times 2^9, as the device packs them, so that
+    the lo plane of |w| ~ 0.03 weights stays a normal half; `mm` undoes the scale on the fp32 result,
+    exactly."""
     if name not in self._wcache:
       w = self.p[name]
-      sc = 1.0
-      if self.precision.startswith('f16'):
-        top = float(np.abs(self.xp.to_numpy(w)).max())
-        sc = 2.0 ** math.floor(math.log2(16384.0 / top)) if top > 0 else 1.0
+      sc = self.W_SCALE_F16 if self.precision.startswith('f16') else 1.0
       self._wcache[name] = (self._split(w * sc) if sc != 1.0 else self._split(w), sc)
     return self._wcache[name]
 
