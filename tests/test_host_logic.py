@@ -108,3 +108,24 @@ def test_checkpoint_loader_paths(tmp_path):
   assert step2 == 1234 and all(np.array_equal(p2[k], params[k]) for k in params)
   with pytest.raises(ValueError):       # not a directory (T5X dirs are read: tests/test_checkpoints.py)
     inference._load_checkpoint('/some/t5x/checkpoint_500000', spec)
+
+
+def test_chunking_properties():
+  """sharding.contiguous_chunk / deal_round_robin over every (segments, world) up to 40 x 12: the chunks tile
+  [0, n) in rank order without gaps, sizes differ by at most one with the larger ones first (the sender /
+  receiver conditions of chained_predict rely on it), and round-robin dealing is a partition."""
+  from msd_amd import sharding
+  for n in range(0, 41):
+    for world in range(1, 13):
+      chunks = [sharding.contiguous_chunk(n, r, world) for r in range(world)]
+      assert chunks[0][0] == 0 and chunks[-1][1] == n
+      assert all(chunks[r][1] == chunks[r + 1][0] for r in range(world - 1))
+      sizes = [b - a for a, b in chunks]
+      assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+      # a rank receives the hand-off iff the previous rank sends it (chained_predict's two conditions)
+      for r in range(1, world):
+        recv = 0 < chunks[r][0] < n
+        send = chunks[r - 1][1] < n
+        assert recv == (send and chunks[r - 1][1] > 0)
+      dealt = sorted(i for r in range(world) for i in sharding.deal_round_robin(n, r, world))
+      assert dealt == list(range(n))
