@@ -270,8 +270,8 @@ def _make_random():
     def f(*a, **k):
       raise NotImplementedError('jax.random.%s: not on the deterministic inference path' % name)
     return f
-  for name in ('randint', 'bernoulli'):
-    setattr(m, name, _absent(name))
+  m.bernoulli = lambda key, p=0.5, shape=(): _wrap(_key_rng(key).random(tuple(shape)) < p)
+  m.randint = _absent('randint')
   return m
 
 
@@ -424,15 +424,18 @@ class Module:
       fn = getattr(method, '__func__', method)
     return fn(clone, *args, **kwargs)
 
-  def init(self, rngs, *args, method=None, **kwargs):
+  def init_with_output(self, rngs, *args, method=None, **kwargs):
     global MODE
     prev, MODE = MODE, 'init'
     try:
       variables = {'params': {}}
-      self.apply(variables, *args, method=method, **kwargs)
-      return variables
+      out = self.apply(variables, *args, method=method, **kwargs)
+      return out, variables
     finally:
       MODE = prev
+
+  def init(self, rngs, *args, method=None, **kwargs):
+    return self.init_with_output(rngs, *args, method=method, **kwargs)[1]
 
 
 class Dropout(Module):
@@ -514,14 +517,19 @@ def install():
   linen.partitioning = part
   struct = types.ModuleType('flax.struct')
   struct.dataclass = _struct_dataclass
+  part.AxisMetadata = type('AxisMetadata', (), {})
+  core = types.ModuleType('flax.core')
+  core.freeze = core.unfreeze = lambda tree: tree
   flax = types.ModuleType('flax')
-  flax.linen, flax.struct = linen, struct
+  flax.linen, flax.struct, flax.core = linen, struct, core
   flax._msd_ref_shim = True
+  jnn.initializers = linen.initializers
+  jax.config = types.SimpleNamespace(parse_flags_with_absl=lambda: None, update=lambda *a, **k: None)
 
   sys.modules.update({
       'jax': jax, 'jax.numpy': jnp, 'jax.lax': lax, 'jax.nn': jnn, 'jax.random': jrandom, 'jax.tree': tree,
       'flax': flax, 'flax.linen': linen, 'flax.linen.partitioning': part, 'flax.linen.initializers': linen.initializers,
-      'flax.linen.linear': linear, 'flax.struct': struct,
+      'flax.linen.linear': linear, 'flax.struct': struct, 'flax.core': core, 'jax.nn.initializers': linen.initializers,
   })
 
 
@@ -602,15 +610,42 @@ def load_models():
   t5x_models = importlib.import_module('t5x.models')
   t5x_models.BaseTransformerModel = BaseTransformerModel
   t5x_models.Array = np.ndarray
-  core = types.ModuleType('flax.core')
+  core = sys.modules['flax.core']
   scope = types.ModuleType('flax.core.scope')
   scope.FrozenVariableDict = dict
   core.scope = scope
-  sys.modules['flax'].core = core
-  sys.modules.update({'flax.core': core, 'flax.core.scope': scope})
+  sys.modules['flax.core.scope'] = scope
   ref.audio_codecs = importlib.import_module('music_spectrogram_diffusion.audio_codecs')
   ref.models = importlib.import_module('music_spectrogram_diffusion.models.diffusion.models')
   return ref
+
+
+def install_absl_testing():
+  """absl.testing.{absltest, parameterized} as far as the reference's layers_test.py uses them, over unittest."""
+  import unittest
+
+  def _expand(sets, named):
+    def deco(fn):
+      @functools.wraps(fn)
+      def run(self):
+        for s in sets:
+          kw = dict(s) if isinstance(s, dict) else None
+          label = kw.pop('testcase_name', None) if (kw is not None and named) else None
+          with self.subTest(case=label if label is not None else s):
+            fn(self, **kw) if kw is not None else fn(self, *s)
+      return run
+    return deco
+  absl = types.ModuleType('absl')
+  testing = types.ModuleType('absl.testing')
+  absltest = types.ModuleType('absl.testing.absltest')
+  absltest.TestCase, absltest.main = unittest.TestCase, unittest.main
+  param = types.ModuleType('absl.testing.parameterized')
+  param.TestCase = unittest.TestCase
+  param.parameters = lambda *sets: _expand(sets, False)
+  param.named_parameters = lambda *sets: _expand(sets, True)
+  absl.testing, testing.absltest, testing.parameterized = testing, absltest, param
+  sys.modules.update({'absl': absl, 'absl.testing': testing, 'absl.testing.absltest': absltest,
+                      'absl.testing.parameterized': param})
 
 
 def load_reference():
