@@ -61,12 +61,26 @@ def _fp8_round(xp, lo, kind):
 # fp16 number (|w| ~ 0.03: lo ~ 1e-5 would be subnormal); activations are split as they are, saturating.
 F16_VARIANTS = {
     'f16x3': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noalo_mlp_out': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noalo_attn_out': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noalo_mlp_in': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noalo_qkv': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noalo_outs': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
     'f16x3_noscale': dict(scale_w=False, mm=[(0, 0), (0, 1), (1, 0)]),
     'f16x2_no_alo': dict(scale_w=True, mm=[(0, 0), (0, 1)]),      # activations single fp16 plane: 2 MFMAs per product
     'f16x4': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0), (1, 1)]),
 }
 
 
+# half planes, activation lo plane dropped for SOME GEMMs only (2 MFMAs per product there and a third less
+# activation ingest): which projections tolerate it?  name -> substrings of the weight names affected
+F16_ALO_DROP = {
+    'f16_noalo_mlp_out': ('/mlp/wo/',),                       # A = gated-GELU output g (K = mlp_dim)
+    'f16_noalo_attn_out': ('/out/kernel',),                   # A = attention output (self and cross)
+    'f16_noalo_mlp_in': ('/mlp/wi_',),                        # A = normalised residual y
+    'f16_noalo_qkv': ('/query/', '/key/', '/value/'),         # A = normalised residual y / encodings
+    'f16_noalo_outs': ('/mlp/wo/', '/out/kernel'),
+}
 def _f16(x):
   import torch
   return x.clamp(-65504.0, 65504.0).to(torch.float16).to(x.dtype)
@@ -112,8 +126,14 @@ class StudyModel(fast.FastModel):
         self._wcache[name] = (fast.FastModel._split(self, w), 1.0)
     return self._wcache[name]
 
+  def mm(self, a, name):
+    self._drop_alo = self.variant in F16_ALO_DROP and any(sub in name for sub in F16_ALO_DROP[self.variant])
+    return super().mm(a, name)
+
   def _mm_parts(self, a_parts, w_parts):
     if self.variant in F16_VARIANTS:
+      if getattr(self, '_drop_alo', False):
+        return self.xp.matmul(a_parts[0], w_parts[0]) + self.xp.matmul(a_parts[0], w_parts[1])
       y = 0
       for a, b in F16_VARIANTS[self.variant]['mm']:
         y = y + self.xp.matmul(a_parts[a], w_parts[b])
