@@ -1,8 +1,16 @@
-"""Which of the three split-bf16 products does attention actually need?  CPU study with the oracle's
-precision emulation (test infrastructure): the `small` 1000-step golden segment is re-run with
-attention variants that drop one hi/lo product, and the mel rms against the float64 fixture is
-printed next to the north-star bar (1e-3).  Guides kernel work; changes nothing in the product.
-  python -m tests.diag.precision_study [variant ...]"""
+"""CPU studies of the operand arithmetic with the oracle's precision emulation (test infrastructure): the `small`
+1000-step golden segment (or, `base`, the two chained base_with_context segments) is re-run with a variant of the
+device arithmetic and the mel rms against the float64 fixture is printed next to the north-star bar (1e-3).  The
+emulation has predicted the device to three digits every time it was checked (bf16x3 1.40e-4 / 1.376e-4 measured,
+f16x3 6.77e-5 / 6.82e-5, base segment 0 6.28e-5 / 6.28e-5).  Guides kernel work; changes nothing in the product.
+
+  x3, pv_*, qk_*, q_p_single   bfloat16 planes: which of the three hi / lo products attention needs
+  mm_no_alo, mm_no_wlo         bfloat16 planes: GEMM with one activation / weight plane
+  lo8_*                        bfloat16 hi + fp8 lo planes
+  f16x3, f16x3_noscale, f16x4, f16x2_no_alo      IEEE-half planes (what the device computes in now)
+  f16_noalo_*                  half planes, activation lo plane dropped for one projection class
+
+  python -m tests.diag.precision_study [base] [variant ...]"""
 import os
 import sys
 import time
