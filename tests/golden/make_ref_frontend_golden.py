@@ -12,6 +12,7 @@ For every seeded case of tests/ref_frontend_cases.py:
   -> encode_and_index_events (note_event_data_to_events, note_encoding_state_to_events)
   -> per 256-frame segment: extract_sequence_with_indices (tie token) -> run_length_encode_shifts (velocity, program)
   -> GenericTokenVocabulary._encode
+  -> and back: NoteEncodingWithTiesSpec decoding of the segment tokens -> flush -> notes
 and everything along the way is stored.  tests/test_ref_frontend.py holds the package's frontend/ to it bit for bit.
 
     python tests/golden/make_ref_frontend_golden.py
@@ -118,7 +119,8 @@ def main():
 
   out = {k: [] for k in ('events', 'start', 'end', 'state_events', 'state_idx', 'times', 'val_pitch', 'val_velocity',
                          'val_program', 'val_drum', 'trim_start', 'trim_end', 'trim_pitch', 'instrument',
-                         'seg_tokens', 'seg_vocab_ids')}
+                         'seg_tokens', 'seg_vocab_ids', 'dec_start', 'dec_end', 'dec_pitch', 'dec_velocity', 'dec_program',
+                         'dec_drum', 'dec_instrument')}
   seg_case, meta = [], []
   for i in range(cases.N_CASES):
     c = cases.case(i)
@@ -148,6 +150,9 @@ def main():
       out[k].append(v)
     tie = codec.encode_event(ec.Event('tie', 0))
     encode_shifts = rle.run_length_encode_shifts_fn(codec, state_change_event_types=['velocity', 'program'])
+    spec = nsq.NoteEncodingWithTiesSpec
+    dstate = spec.init_decoding_state_fn()
+    invalid = dropped = 0
     for f0 in range(0, c['n_frames'], cases.SEGMENT_FRAMES):
       f1 = min(f0 + cases.SEGMENT_FRAMES, c['n_frames'])
       feats = {'targets': events, 'event_start_indices': start[f0:f1], 'event_end_indices': end[f0:f1],
@@ -158,13 +163,24 @@ def main():
       out['seg_tokens'].append(toks)
       out['seg_vocab_ids'].append(np.asarray(vocab._encode(toks.tolist()), np.int64))
       seg_case.append(i)
-    meta.append((codec.num_classes, vocab._base_vocab_size, voc.num_embeddings(vocab), tie))
+      # and back: the decoder of the reference on the tokens just made (note_sequences.py:301-408)
+      spec.begin_decoding_segment_fn(dstate)
+      a, b = rle.decode_events(dstate, toks, start_time=f0 / cases.FRAME_RATE, max_time=None, codec=codec,
+                               decode_event_fn=spec.decode_event_fn)
+      invalid, dropped = invalid + a, dropped + b
+    dec = spec.flush_decoding_state_fn(dstate)
+    out['dec_start'].append(np.array([n.start_time for n in dec.notes], np.float64))
+    out['dec_end'].append(np.array([n.end_time for n in dec.notes], np.float64))
+    for k, f in (('dec_pitch', lambda n: n.pitch), ('dec_velocity', lambda n: n.velocity), ('dec_program', lambda n: n.program),
+                 ('dec_drum', lambda n: int(bool(n.is_drum))), ('dec_instrument', lambda n: n.instrument)):
+      out[k].append([f(n) for n in dec.notes])
+    meta.append((codec.num_classes, vocab._base_vocab_size, voc.num_embeddings(vocab), tie, invalid, dropped))
   save = {}
   for k, rows in out.items():
-    dtype = np.float64 if k in ('times', 'trim_start', 'trim_end') else np.int64
+    dtype = np.float64 if k in ('times', 'trim_start', 'trim_end', 'dec_start', 'dec_end') else np.int64
     save[k], save[k + '_off'] = ragged(rows, dtype)
   save['seg_case'] = np.array(seg_case, np.int64)
-  save['meta'] = np.array(meta, np.int64)     # per case: codec classes, base vocabulary size, num_embeddings, tie token
+  save['meta'] = np.array(meta, np.int64)     # per case: codec classes, base vocabulary size, num_embeddings, tie token, invalid / dropped events of the decode
   np.savez_compressed(os.path.join(HERE, 'ref_frontend.npz'), **save)
   print('%d cases, %d segments, %d events, %d tokens' % (cases.N_CASES, len(seg_case), len(save['events']), len(save['seg_tokens'])))
 

@@ -3,7 +3,8 @@ event_codec.py, vocabularies.py) executed on 48 seeded random note sets over sta
 seqio (tests/golden/make_ref_frontend_golden.py).  The package's frontend/ must reproduce every intermediate bit
 for bit: instrument assignment, overlap trimming, the (time, value) event list and its ordering, the unit-shift event
 stream with its frame indices and state dumps, and -- per 256-frame segment -- the tie-prefixed, run-length encoded
-tokens and their vocabulary ids; plus codec / vocabulary sizes."""
+tokens and their vocabulary ids; then the way back (NoteEncodingWithTiesSpec decoding of those tokens: the decoded
+notes, invalid / dropped counts); plus codec / vocabulary sizes."""
 import os
 
 import numpy as np
@@ -33,7 +34,7 @@ def test_frontend_reproduces_the_references_tokenisation(gold):
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=c['num_velocity_bins']))
     vocab = vocabularies.vocabulary_from_codec(codec)
     tie = codec.encode_event(event_codec.Event('tie', 0))
-    assert (codec.num_classes, vocab._base_vocab_size, vocabularies.num_embeddings(vocab), tie) == tuple(g['meta'][i])
+    assert (codec.num_classes, vocab._base_vocab_size, vocabularies.num_embeddings(vocab), tie) == tuple(g['meta'][i][:4])
     ns = note_sequences.note_arrays_to_note_sequence(
         c['onsets'].tolist(), c['pitches'].tolist(), c['offsets'].tolist(), c['velocities'].tolist(),
         c['programs'].tolist(), c['is_drums'].tolist())
@@ -57,6 +58,9 @@ def test_frontend_reproduces_the_references_tokenisation(gold):
                      (state_idx, 'state_idx')):
       np.testing.assert_array_equal(np.asarray(got), _row(g, key, i), err_msg='case %d %s' % (i, key))
     encode_shifts = run_length_encoding.run_length_encode_shifts_fn(codec, state_change_event_types=['velocity', 'program'])
+    spec = note_sequences.NoteEncodingWithTiesSpec
+    dstate = spec.init_decoding_state_fn()
+    invalid = dropped = 0
     for f0 in range(0, c['n_frames'], cases.SEGMENT_FRAMES):
       f1 = min(f0 + cases.SEGMENT_FRAMES, c['n_frames'])
       assert int(g['seg_case'][seg]) == i
@@ -67,7 +71,19 @@ def test_frontend_reproduces_the_references_tokenisation(gold):
       feats = encode_shifts(feats)
       np.testing.assert_array_equal(np.asarray(feats['targets']), _row(g, 'seg_tokens', seg), err_msg='case %d frame %d' % (i, f0))
       np.testing.assert_array_equal(vocab.encode(np.asarray(feats['targets']).tolist()), _row(g, 'seg_vocab_ids', seg))
+      # and back, with the package's decoder on the same tokens
+      spec.begin_decoding_segment_fn(dstate)
+      a, b = run_length_encoding.decode_events(dstate, np.asarray(feats['targets']), f0 / cases.FRAME_RATE, None, codec,
+                                               spec.decode_event_fn)
+      invalid, dropped = invalid + a, dropped + b
       seg += 1
+    dec = spec.flush_decoding_state_fn(dstate)
+    assert (invalid, dropped) == tuple(g['meta'][i][4:6])
+    np.testing.assert_array_equal([n.start_time for n in dec.notes], _row(g, 'dec_start', i), err_msg='case %d' % i)
+    np.testing.assert_array_equal([n.end_time for n in dec.notes], _row(g, 'dec_end', i))
+    for key, f in (('dec_pitch', lambda n: n.pitch), ('dec_velocity', lambda n: n.velocity), ('dec_program', lambda n: n.program),
+                   ('dec_drum', lambda n: int(bool(n.is_drum))), ('dec_instrument', lambda n: n.instrument)):
+      assert [f(n) for n in dec.notes] == _row(g, key, i).tolist(), (i, key)
   assert seg == len(g['seg_case'])
 
 
