@@ -62,3 +62,35 @@ def test_synthetic_midi_workload():
     assert 100 < n < 2048 and t[0, n - 1] == 1 and t.max() < 1536
   again = bench.synthetic_midi_tokens(spec, 7, 3)
   assert all(np.array_equal(a, b) for a, b in zip(toks, again))
+
+
+def test_roofline_json_covers_every_kernel_class_of_the_step():
+  """profiles/roofline.json (tools/make_roofline.py) must hold every kernel class of the DDPM step with a duration,
+  a FLOP-rate fraction and -- for the MFMA classes -- utilisation and traffic; the kernel names of the committed
+  trace must all classify (a renamed kernel or template argument would silently drop a class)."""
+  import csv
+  import importlib.util
+  import json
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('make_roofline', os.path.join(root, 'tools', 'make_roofline.py'))
+  mr = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mr)
+  doc = json.load(open(os.path.join(root, 'profiles', 'roofline.json')))
+  want = {'gemm_mlp_in_geglu', 'gemm_mlp_out', 'gemm_qkv', 'gemm_attn_out+gemm_cross_out', 'gemm_cross_q', 'attn_self',
+          'attn_cross', 'attn_cross_merge', 'final_proj_f32', 'in_proj_f32', 'sampler_step'}
+  assert set(doc['per_class']) == want
+  for cls, e in doc['per_class'].items():
+    assert e['avg_us'] > 1.0 and e['calls'] >= 1000, cls
+    if cls.startswith(('gemm_', 'attn_self', 'attn_cross')) and cls != 'attn_cross_merge':
+      assert 0 < e['frac'] < 1 and 0 < e['mfma_util'] < 1 and e['fabric_bytes_per_launch'] > 0, cls
+  assert len(doc['library_sha']) == 16
+  trace = os.path.join(root, 'profiles', '%s_bench_kernel_stats.csv' % doc['tag'])
+  seen = set()
+  with open(trace) as f:
+    for r in csv.DictReader(f):
+      if 'msd::' in r['Name'] and int(r['Calls']) >= 1000:      # the step's kernels (the encoders' run far fewer times)
+        cls = mr.classify(r['Name'])
+        assert cls is not None, r['Name']
+        seen.add(cls)
+  assert seen == want
