@@ -1,6 +1,6 @@
 """Benchmark of the hot path: mel-frames/sec (+ xRTF) of 1000-step DDPM synthesis.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: ONE 256-frame (5.12 s)
@@ -252,6 +252,73 @@ def batched_leg(spec, args):
           'note': 'same kernels, %d independent songs batched per handle; not the headline workload (SURVEY 8: B=1)' % nb}
 
 
+def small_leg(args):
+  """BASELINE.json configs[1] beside the headline: `small` (no context), 1000-step DDPM, one GPU, a synthetic
+  60 s song = 12 independent 256-frame segments one after the other.  One warm-up segment
+  (restore + graph capture, excluded like the reference's first segment), then the 12 timed ones."""
+  import torch
+  import msd_amd
+  spec = msd_amd.config.preset('small', num_steps=args.num_steps, cfg_weight=args.cfg_weight)
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=1, precision=args.precision)
+  t_frames = spec.task_feature_lengths['targets']
+  n = args.small_segments
+  segs = [msd_amd.synthetic.segment_tokens(spec, 5000 + k) for k in range(n + 1)]
+  model.predict({'encoder_input_tokens': segs[0]}, seed=0, segment=0, return_torch=True)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  smp = 0.0
+  for k in range(1, n + 1):
+    out, _ = model.predict({'encoder_input_tokens': segs[k]}, seed=0, segment=k, return_torch=True)
+    smp += model.last_timing['sample_s']
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  assert torch.isfinite(out).all(), 'non-finite mel output (small)'
+  return {'value': round(n * t_frames / dt, 3), 'unit': 'mel-frames/sec', 'xRTF': round(n * t_frames * 320 / 16000.0 / dt, 4),
+          'ms_per_step': round(dt / n * 1e3, 3), 'segments': n,
+          'ms_per_ddpm_step': round(smp / n / args.num_steps * 1e3, 5),
+          'config': {'workload': 'small (no context), %d-step DDPM, CFG w=%g, 1 song per GPU, %d independent segments of '
+                                 '%d frames (60 s of audio)' % (args.num_steps, args.cfg_weight, n, t_frames),
+                     'precision': args.precision}}
+
+
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def self_launch(args, argv):
+  """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks ourselves --
+  the same command the driver's own launcher would run -- and hand back its exit code.  Rank 0 of the children
+  prints the one JSON line on the stdout they inherit."""
+  import subprocess
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL between processes needs it on this driver
+  env.setdefault('OMP_NUM_THREADS', '4')
+  return subprocess.run(cmd, env=env).returncode
+
+
+def _resolve(name):
+  """'package.module:attr' -> the object (the CPU test leg swaps the model class this way)."""
+  import importlib
+  mod, attr = name.split(':')
+  return getattr(importlib.import_module(mod), attr)
+
+
+def _sync(device=None):
+  """torch.cuda.synchronize() when the run is on a GPU (the CPU / gloo test leg has nothing to wait for)."""
+  import torch
+  if device is not None and str(device) == 'cpu':
+    return
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+
+
 def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
   """Untimed evidence that the hand-off primitive of --mode chained/wavefront works on this node: the
   128 KiB context message goes rank r -> r+1 (device to device, dist.send/recv = RCCL point-to-point
@@ -259,21 +326,21 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
   import torch
   try:
     buf = torch.full(shape, float(rank), dtype=torch.float32, device=device)
-    torch.cuda.synchronize()
+    _sync(device)
     dist.barrier()
     ok = True
     t0 = time.perf_counter()
     for k in range(rounds + 1):
       if k == 1:   # round 0 opens the connections
-        torch.cuda.synchronize()
+        _sync(device)
         t0 = time.perf_counter()
       if rank > 0:
         dist.recv(buf, src=rank - 1)
-        torch.cuda.synchronize()
+        _sync(device)
         ok = ok and bool((buf == float(rank - 1) + k).all())
       if rank + 1 < world:
         dist.send(torch.full(shape, float(rank) + k, dtype=torch.float32, device=device), dst=rank + 1)
-    torch.cuda.synchronize()
+    _sync(device)
     dt = time.perf_counter() - t0
     flag = torch.tensor([1.0 if ok else 0.0], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -307,7 +374,17 @@ def main():
   ap.add_argument('--profile-steps', type=int, default=3)
   ap.add_argument('--batched-songs', type=int, default=8,
                   help='extra leg: this many songs per GPU in one handle (0/1 = skip); N=1 runs only')
+  ap.add_argument('--small-segments', type=int, default=12,
+                  help="extra leg: BASELINE config 2, the `small` no-context model over this many segments (0 = skip); N=1 runs only")
+  ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                  help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the product); 'gloo' is for the CPU test of the launcher")
+  ap.add_argument('--model-factory', default='msd_amd:InferenceModel',
+                  help='module:attr of the InferenceModel class (tests swap in a CPU stand-in to exercise the multi-rank plumbing)')
   args = ap.parse_args()
+
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    # started plainly (the driver's `python bench.py --gpus N`): become the launcher of N ranks
+    raise SystemExit(self_launch(args, sys.argv[1:]))
 
   import torch
   import msd_amd
@@ -317,18 +394,22 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-  torch.cuda.set_device(local_rank)
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or plainly, without '
+                     'torch.distributed.run)' % (args.gpus, world, args.gpus))
+  on_gpu = args.dist_backend == 'nccl'
+  if on_gpu:
+    torch.cuda.set_device(local_rank)
   dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    if on_gpu:
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
 
   spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
-  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
+  model = _resolve(args.model_factory)('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
   nb = args.batch
   t_frames = spec.task_feature_lengths['targets']
   c_len = model.targets_context_length
@@ -364,10 +445,10 @@ def main():
 
   for k in range(args.warmup):
     run_segment(k)
-  torch.cuda.synchronize()
+  _sync(model.device)
   if dist is not None:
     dist.barrier()
-  torch.cuda.synchronize()
+  _sync(model.device)
   t0 = time.perf_counter()
   enc_s = smp_s = 0.0
   ctx_shape = (1, c_len or 0, 128)
@@ -388,14 +469,14 @@ def main():
     song = [t[:1] for t in song_tokens(0, world * args.steps)]
     a, b = sharding.contiguous_chunk(len(song), rank, world)
     out = model.predict_sequence(song[a:b], first_segment_index=a, return_torch=True)
-  torch.cuda.synchronize()
+  _sync(model.device)
   if dist is not None:
     dist.barrier()
-  torch.cuda.synchronize()
+  _sync(model.device)
   elapsed = time.perf_counter() - t0
-  assert torch.isfinite(out).all(), 'non-finite mel output'
+  assert torch.isfinite(torch.as_tensor(out)).all(), 'non-finite mel output'
   if dist is not None:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   handoff = handoff_check(dist, rank, world, model.device, (1, c_len, 128)) if (dist is not None and c_len) else None
@@ -413,8 +494,11 @@ def main():
     # make sure the profiled steps see this rank's last replica-style encode (chained modes end elsewhere)
     if mode != 'replicas':
       run_segment(n_seg - 1)
-    with torch.cuda.device(model.device):
-      prof = nm.profile_steps(nb, args.profile_steps, stream=model._stream.cuda_stream)
+    if on_gpu:
+      with torch.cuda.device(model.device):
+        prof = nm.profile_steps(nb, args.profile_steps, stream=model._stream.cuda_stream)
+    else:
+      prof = nm.profile_steps(nb, args.profile_steps)
     flops = {k: v * nb for k, v in class_flops(spec, s_valid, passes).items()}
     abytes = {k: v * nb for k, v in class_bytes(spec, s_valid, passes, 2 if args.precision.endswith('x3') else 1).items()}
     per_class = {}
@@ -488,6 +572,8 @@ def main():
       result['handoff_check'] = handoff
     if world == 1 and args.batched_songs > 1 and nb == 1:
       result['batched'] = batched_leg(spec, args)
+    if world == 1 and args.small_segments > 0 and nb == 1 and args.preset != 'small':
+      result['small'] = small_leg(args)
     if world == 1 and not args.no_cpu_baseline:
       batch = {'encoder_input_tokens': segs[-1][:1]}
       if c_len is not None:

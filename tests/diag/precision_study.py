@@ -9,6 +9,10 @@ f16x3 6.77e-5 / 6.82e-5, base segment 0 6.28e-5 / 6.28e-5).  Guides kernel work;
   lo8_*                        bfloat16 hi + fp8 lo planes
   f16x3, f16x3_noscale, f16x4, f16x2_no_alo      IEEE-half planes (what the device computes in now)
   f16_noalo_*                  half planes, activation lo plane dropped for one projection class
+  f16_noqlo, f16_noplo, f16_noqplo, f16_noqplo_self, f16_noqplo_cross
+                               half planes, the QUERY-side lo planes of attention dropped (Q in S = Q.K^T, P in
+                               O = P.V): 2 MFMAs per product instead of 3 and no split of P (VERDICT r02 item 5;
+                               the bfloat16-plane rows qk_no_qlo / pv_no_plo above predate the half planes)
 
   python -m tests.diag.precision_study [base] [variant ...]"""
 import os
@@ -77,6 +81,19 @@ F16_VARIANTS = {
     'f16x3_noscale': dict(scale_w=False, mm=[(0, 0), (0, 1), (1, 0)]),
     'f16x2_no_alo': dict(scale_w=True, mm=[(0, 0), (0, 1)]),      # activations single fp16 plane: 2 MFMAs per product
     'f16x4': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0), (1, 1)]),
+    'f16_noqlo': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noplo': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noqplo': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noqplo_self': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noqplo_cross': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+}
+
+# half planes, query-side lo planes of ATTENTION dropped: name -> (QK products, PV products, where)
+_X3 = [(0, 0), (0, 1), (1, 0)]
+_NOL = [(0, 0), (0, 1)]          # left operand (Q resp. P) single plane
+F16_ATT = {
+    'f16_noqlo': (_NOL, _X3, 'all'), 'f16_noplo': (_X3, _NOL, 'all'), 'f16_noqplo': (_NOL, _NOL, 'all'),
+    'f16_noqplo_self': (_NOL, _NOL, 'self'), 'f16_noqplo_cross': (_NOL, _NOL, 'cross'),
 }
 
 
@@ -156,6 +173,13 @@ class StudyModel(fast.FastModel):
   def _attend(self, q, k, v):
     xp = self.xp
     qk, pv = VARIANTS.get(self.variant, VARIANTS['x3'])
+    if self.variant in F16_ATT:
+      qk, pv, where = F16_ATT[self.variant]
+      # decoder self-attention has as many keys as queries (and encoder self-attention too); cross-attention
+      # is the only call with a different key count on these configs
+      is_self = q.shape[0] == k.shape[0]
+      if (where == 'self' and not is_self) or (where == 'cross' and is_self):
+        qk, pv = _X3, _X3
     def split(a):
       if self.variant in F16_VARIANTS:
         return _split_f16(a)

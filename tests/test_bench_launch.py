@@ -1,0 +1,57 @@
+"""`python bench.py --gpus N` must run by ITSELF: started without torch.distributed.run it
+becomes the launcher of its N ranks.  Exercised here on CPU: gloo backend and a stand-in model class
+(tests/bench_stub.py) in place of the HIP synthesizer -- everything else is the product's bench.py: rendezvous on
+127.0.0.1, barriers, the --mode drivers of sharding.py (replicas / chained / wavefront / masked), the hand-off probe,
+max-over-ranks timing and exactly one JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = ['--dist-backend', 'gloo', '--model-factory', 'tests.bench_stub:StubInferenceModel', '--no-cpu-baseline',
+        '--batched-songs', '0', '--small-segments', '0']
+
+
+def run_bench(*flags, env_extra=None, timeout=240):
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  env.update(env_extra or {})
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags) + STUB, cwd=ROOT, env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+  return p
+
+
+def json_lines(stdout):
+  return [json.loads(l) for l in stdout.splitlines() if l.startswith('{') and l.rstrip().endswith('}')]
+
+
+@pytest.mark.parametrize('mode', ['replicas', 'chained', 'wavefront', 'masked'])
+def test_plain_command_starts_its_own_ranks(mode):
+  p = run_bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--mode', mode)
+  assert p.returncode == 0, p.stderr[-2000:]
+  lines = json_lines(p.stdout)
+  assert len(lines) == 1, p.stdout            # rank 0 only
+  d = lines[0]
+  assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+  assert d['metric'] == 'mel-frames/sec' and d['value'] > 0 and d['higher_is_better'] is True
+  assert d['config']['mode'] == mode
+  # whole-job aggregate: 2 ranks x 3 segments x 256 frames in ms_per_step * 3
+  assert abs(d['value'] - 2 * 3 * 256 / (d['ms_per_step'] * 3e-3)) / d['value'] < 1e-3
+  h = d['handoff_check']                       # the 128 KiB context message went rank 0 -> 1, content verified
+  assert h['ok'] is True and h['hops'] == 1 and h['message_bytes'] == 256 * 128 * 4
+  assert 'cpu_baseline' not in d and 'batched' not in d    # N = 1 legs only
+
+
+def test_single_rank_needs_no_launcher():
+  p = run_bench('--gpus', '1', '--steps', '2', '--warmup', '1')
+  assert p.returncode == 0, p.stderr[-2000:]
+  d, = json_lines(p.stdout)
+  assert d['n_gpus'] == 1 and 'handoff_check' not in d
+  assert d['roofline']['kernel'] == 'gemm_mlp_in_geglu' and d['roofline']['bound'] == 'mfma'
+
+
+def test_world_size_mismatch_is_an_error():
+  p = run_bench('--gpus', '2', '--steps', '1', env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+  assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
