@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 2
+#define MSD_AMD_ABI_VERSION 3   /* 3: MSD_ERR_RANGE; distinct values for the bfloat16-plane precisions; msd_op_gemm_h16 */
 
 typedef struct msd_model msd_model; /* opaque */
 
@@ -48,7 +48,12 @@ typedef enum msd_status {
   MSD_ERR_SHAPE_MISMATCH = 3,   /* -> ValueError */
   MSD_ERR_BAD_STATE = 4,        /* call order violated -> RuntimeError */
   MSD_ERR_HIP = 5,              /* HIP runtime failure -> RuntimeError */
-  MSD_ERR_UNSUPPORTED = 6       /* valid in the reference, not built here -> NotImplementedError */
+  MSD_ERR_UNSUPPORTED = 6,      /* valid in the reference, not built here -> NotImplementedError */
+  MSD_ERR_RANGE = 7             /* an ACTIVATION left the range of the IEEE-half operand planes (|x| > 65504) during
+                                   this call: its result is invalid.  The reference computes in float32
+                                   (gin/models/diffusion/context/t5_base.gin:72) and has no such limit; the way out is
+                                   the bfloat16-plane build (MSD_PREC_BF16X3, libmsd_amd_bf16.so) -> msd RangeError
+                                   (an ArithmeticError) in the Python layer */
 } msd_status;
 
 /* Arithmetic of the transformer GEMMs / attention.  Residual stream, RMSNorm
@@ -57,11 +62,15 @@ typedef enum msd_status {
 typedef enum msd_precision {
   MSD_PREC_F16 = 0,    /* one IEEE-half plane per operand (v_mfma_f32_*_f16), fp32 accumulate: fast, not parity-grade */
   MSD_PREC_F16X3 = 1,  /* operands split hi + lo half planes (22 significand bits), 3 MFMAs per product
-                          (hi.hi + hi.lo + lo.hi): float32-class results -- the parity mode.  Conversions
-                          saturate at 65504; weights are packed times 2^9 and the accumulators rescaled. */
-  /* names of ABI <= 2 builds, whose planes were bfloat16 (same values, same meaning of "1 plane" / "hi + lo") */
-  MSD_PREC_BF16 = MSD_PREC_F16,
-  MSD_PREC_BF16X3 = MSD_PREC_F16X3
+                          (hi.hi + hi.lo + lo.hi): float32-class results -- the parity mode and the default.
+                          Weights must satisfy |w| < 128 (packed times 2^9; checked by msd_finalize_weights ->
+                          MSD_ERR_UNSUPPORTED); activations |x| <= 65504 (checked on every conversion ->
+                          MSD_ERR_RANGE from the call that saw it). */
+  MSD_PREC_BF16 = 2,   /* one bfloat16 plane per operand */
+  MSD_PREC_BF16X3 = 3  /* hi + lo bfloat16 planes (16 significand bits, float32's exponent range: no range limit) */
+  /* The plane FORMAT is a property of the library build: libmsd_amd.so implements the two half precisions,
+   * libmsd_amd_bf16.so (same sources, same ABI) the two bfloat16 ones; msd_create returns MSD_ERR_UNSUPPORTED for a
+   * precision of the other build (ABI <= 2 aliased the names and silently ran whatever planes the library had). */
 } msd_precision;
 
 typedef enum msd_sampler_kind {
@@ -164,7 +173,9 @@ int msd_finalize_weights(msd_model* m, void* stream);
 int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_dev,
                const int32_t* ctx_mask, void* stream);
 
-/* eval_scan (diffusion_utils.py:456-476) + scale_to_features (models.py:395).
+/* eval_scan (diffusion_utils.py:456-476) + scale_to_features (models.py:395).  SYNCHRONISES `stream` before it
+ * returns (ABI 3): behind that one wait it reads the handle's half-plane range flag, so that a run whose
+ * activations left the plane range fails THIS call with MSD_ERR_RANGE instead of handing back a wrong spectrogram.
  *   init_z_dev float [batch,T,n] or NULL  -> generated (Philox, see msd_fill_normal)
  *   noise_dev  float [N,batch,T,n] or NULL -> generated; noise_dev[i] is the draw
  *              used at scan index i (diffusion_utils.py:389-390)
@@ -209,9 +220,14 @@ int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t ma
 int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** names_out,
                       double* ms_out, int64_t* launches_out, void* stream);
 
-/* Standalone ops (the building blocks, for unit parity tests). All device ptrs. */
+/* Standalone ops (the building blocks, for unit parity tests). All device ptrs.  They synchronise and fail like the
+ * model does: weights beyond the half-plane range -> MSD_ERR_UNSUPPORTED, activations beyond it -> MSD_ERR_RANGE,
+ * a `precision` of the other library build -> MSD_ERR_UNSUPPORTED. */
+int msd_op_gemm_h16(int precision, const float* a_dev, const float* w_dev, float* c_dev,
+                    int m, int n, int k, void* stream); /* C = A[m,k] @ W[k,n] on 16-bit operand planes */
+/* deprecated ABI <= 2 name of msd_op_gemm_h16 (the planes were bfloat16 then) */
 int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev,
-                     int m, int n, int k, void* stream); /* C = A[m,k] @ W[k,n] */
+                     int m, int n, int k, void* stream);
 int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev,
                     int m, int n, int k, void* stream);
 int msd_op_attention(int precision, const float* q_dev, const float* k_dev,

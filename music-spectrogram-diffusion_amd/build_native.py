@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libmsd_amd.so')
 LIBS = {'f16': (LIB, []), 'bf16': (os.path.join(CSRC, 'libmsd_amd_bf16.so'), ['-DMSD_PLANE_BF16=1'])}
 SOURCES = ['msd_api.hip']
-HEADERS = ['common.h', 'chain.h', 'gemm_bf16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
+HEADERS = ['common.h', 'chain.h', 'gemm_h16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
            os.path.join('..', '..', 'include', 'msd_amd.h')]
 
 
@@ -40,16 +40,42 @@ def needs_build(lib: str = LIB) -> bool:
   return False
 
 
+def check_prefetch_registers(listing: str) -> str:
+  """The weight prefetch (csrc/gemm_h16.h prefetch_weights) loads from inline asm into registers the compiler does
+  not know are written late; a compiler that copied or reused one of them would produce a library that corrupts
+  its own epilogue.  tools/check_prefetch_regs.py verifies the DEVICE LISTING OF THE BINARY BEING BUILT (whatever
+  ROCm version builds it); an unsafe listing fails the build."""
+  tool = os.path.join(os.path.dirname(HERE), 'tools', 'check_prefetch_regs.py')
+  out = subprocess.run([sys.executable, tool, listing], capture_output=True, text=True)
+  if out.returncode != 0:
+    raise RuntimeError('prefetch register check failed on %s:\n%s' % (listing, out.stdout[-3000:]))
+  return out.stdout.strip().split('\n')[-1]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
-  """Builds both libraries (each only if older than its sources); returns the default one."""
+  """Builds both libraries (each only if older than its sources); returns the default one.  Each compile keeps
+  its device listing (-save-temps, in a scratch directory) and runs the prefetch register check on it."""
+  import tempfile
   for lib, defs in LIBS.values():
     if not force and not needs_build(lib):
       continue
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-fno-gpu-rdc', '-Wno-unused-result'] + defs + ['-o', lib] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-      print('[build_native]', ' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    with tempfile.TemporaryDirectory(prefix='msd_build_') as tmp:
+      out = os.path.join(tmp, os.path.basename(lib))
+      cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-save-temps',
+             '-fno-gpu-rdc', '-Wno-unused-result', '-I', CSRC] + defs + ['-o', out] + [os.path.join(CSRC, s) for s in SOURCES]
+      if verbose:
+        print('[build_native]', ' '.join(cmd), flush=True)
+      subprocess.run(cmd, check=True, cwd=tmp)
+      listings = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith('gfx950.s')]
+      if not listings:
+        raise RuntimeError('no device listing next to %s: cannot verify the prefetch registers' % out)
+      for l in listings:
+        verdict = check_prefetch_registers(l)
+        if verbose:
+          print('[build_native] prefetch registers:', verdict, flush=True)
+      shutil.copyfile(out, lib + '.tmp')
+      os.chmod(lib + '.tmp', 0o755)
+      os.replace(lib + '.tmp', lib)
   return LIB
 
 

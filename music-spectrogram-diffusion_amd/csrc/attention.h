@@ -28,7 +28,7 @@
 // per-lane SOURCE address.
 #pragma once
 #include "common.h"
-#include "gemm_bf16.h"
+#include "gemm_h16.h"
 
 namespace msd {
 
@@ -51,7 +51,9 @@ struct AttnParams {
   float* part_o;        // [ksplit][rows][heads*64]
   float* part_ml;       // [ksplit][rows][heads][2]
   int total_rows;       // rows of q over all segments
-  WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_bf16.h)
+  WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_h16.h)
+  unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
+  unsigned sat_tag = 1;
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -239,17 +241,9 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
       for (int ks = 0; ks < 2; ++ks) {
         uint32_t wh[4], wl[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          h16_t h0, l0, h1, l1;
-          if (NP == 2) {
-            split_h16(pv[8 * ks + 2 * j], h0, l0);
-            split_h16(pv[8 * ks + 2 * j + 1], h1, l1);
-            wl[j] = pack2(l0, l1);
-          } else {
-            h0 = f2h(pv[8 * ks + 2 * j]);
-            h1 = f2h(pv[8 * ks + 2 * j + 1]);
-          }
-          wh[j] = pack2(h0, h1);
+        for (int j = 0; j < 4; ++j) {   // softmax weights are in [0, 1]: no range check
+          if (NP == 2) split2_h16(pv[8 * ks + 2 * j], pv[8 * ks + 2 * j + 1], wh[j], wl[j]);
+          else wh[j] = cvt2_h16(pv[8 * ks + 2 * j], pv[8 * ks + 2 * j + 1]);
         }
         pf[0][ks] = as_frag(make_uint4(wh[0], wh[1], wh[2], wh[3]));
         if (NP == 2) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
@@ -283,7 +277,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
-  PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_bf16.h WeightPrefetch)
+  PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_h16.h WeightPrefetch)
   {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     prefetch_weights<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], pf_keep);
@@ -334,7 +328,9 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
-      store_h16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v);
+      RangeCheck rc;
+      store_h16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v, rc);
+      rc.commit(p.sat, p.sat_tag);
     } else {
       const int heads = gridDim.x;
       float* po = p.part_o + (((size_t)ks * p.total_rows + row) * heads + head) * 64 + d0;
@@ -375,7 +371,9 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
-  store_h16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v);
+  RangeCheck rc;
+  store_h16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v, rc);
+  rc.commit(p.sat, p.sat_tag);
 }
 
 template <int NP, int NS, int QB>
@@ -408,7 +406,7 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   // a block, 32-row blocks (twice as many) finish sooner
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
   constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
-  // one instantiation per prefetch kind (gemm_bf16.h); the single-plane mode never prefetches
+  // one instantiation per prefetch kind (gemm_h16.h); the single-plane mode never prefetches
   constexpr int PFW = NP == 2 ? 1 : 0;   // attention launches carry at most one target
   const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);

@@ -13,7 +13,7 @@
 // needed; the kernel boundary stays only where rows mix (self-attention needs the K/V of every row).
 // Operands another block of the same launch produced are loaded with sc1 (gemm_tile<.., CP = 16>).
 #pragma once
-#include "gemm_bf16.h"
+#include "gemm_h16.h"
 
 namespace msd {
 
@@ -68,9 +68,9 @@ struct MlpChainParams {
 
 template <int NP, int QKV_BN>
 constexpr int mlp_chain_smem() {
-  constexpr int a = gemm_bf16_dma_smem<NP, 64, 128, 3, EpiGeglu<NP>>();
-  constexpr int b = gemm_bf16_dma_smem<NP, 64, 32, 4, EpiResidualNorm<NP>>();
-  constexpr int c = gemm_bf16_dma_smem<NP, 64, QKV_BN, 3, EpiQKV<NP>>();
+  constexpr int a = gemm_h16_dma_smem<NP, 64, 128, 3, EpiGeglu<NP>>();
+  constexpr int b = gemm_h16_dma_smem<NP, 64, 32, 4, EpiResidualNorm<NP>>();
+  constexpr int c = gemm_h16_dma_smem<NP, 64, QKV_BN, 3, EpiQKV<NP>>();
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 

@@ -17,7 +17,8 @@ constexpr int kWave = 64;
 // significand bits instead of bfloat16's 16, which puts the split-operand mode on the float32 oracle's error
 // (6.8e-5 against 1.4e-4 on the 1000-step segment; same bytes, same MFMA count).  Half has 5 exponent
 // bits, so
-//   * conversions saturate at +-65504 (v_cvt_f16_f32 alone would return inf); hi + lo covers |x| < 131008;
+//   * an activation with |x| > 65504 does not fit; it is DETECTED (RangeCheck below, one flag word per handle) and
+//     msd_encode / msd_sample then fail with MSD_ERR_RANGE, pointing at the bfloat16-plane build;
 //   * weights are packed multiplied by kWScale and every GEMM multiplies its fp32 accumulators by kWScaleInv (powers
 //     of two: exact), so that the lo plane of |w| ~ 0.03 weights is a NORMAL half (7e-6 would be subnormal: 2
 //     significant bits).  |w| < 128 is representable (checked at load time: msd_finalize_weights).
@@ -32,31 +33,45 @@ typedef __bf16 plane_elem;
 #define MSD_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define MSD_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 constexpr float kWScale = 1.0f, kWScaleInv = 1.0f, kPlaneMax = 3.0e38f;
+constexpr bool kPlaneSaturates = false;
 constexpr const char* kPlaneName = "bfloat16 planes";
-
-// round-to-nearest-even float -> bf16 bits.  The native cast lowers to v_cvt_pk_bf16_f32 (two values per
-// instruction); hand-written bit arithmetic costs ~8 VALU ops per value and made the attention kernel VALU-bound.
-__device__ __forceinline__ h16_t f2h(float f) {
-  const __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(h16_t, b);
-}
-__device__ __forceinline__ float h2f(h16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 #else
 typedef _Float16 plane_elem;
 #define MSD_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define MSD_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 constexpr float kWScale = 512.0f, kWScaleInv = 1.0f / 512.0f, kPlaneMax = 65504.0f;
+constexpr bool kPlaneSaturates = true;
 constexpr const char* kPlaneName = "half planes";
-
-// round-to-nearest-even float -> half bits, saturating
-__device__ __forceinline__ h16_t f2h(float f) {
-  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
-  return __builtin_bit_cast(h16_t, h);
-}
-__device__ __forceinline__ float h2f(h16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 #endif
 
-// hi/lo split: x ~= hi + lo with hi = plane(x), lo = plane(x - hi)
+typedef plane_elem plane2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even float -> plane bits / back.  NOT saturating: a half-plane conversion of |x| > 65504 gives
+// inf -- every conversion site of an ACTIVATION therefore feeds a RangeCheck (below), and a flagged msd_sample /
+// msd_encode fails with MSD_ERR_RANGE instead of returning a wrong spectrogram.  (Round 2 clamped silently, with two
+// v_med3_f32 per split; the reference is float32 and has no such failure mode: gin/.../t5_base.gin:72.)
+__device__ __forceinline__ h16_t f2h(float f) { return __builtin_bit_cast(h16_t, (plane_elem)f); }
+__device__ __forceinline__ float h2f(h16_t b) { return (float)__builtin_bit_cast(plane_elem, b); }
+
+// two values -> one packed dword of the hi plane (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: one instruction)
+__device__ __forceinline__ uint32_t cvt2_h16(float a, float b) {
+  const f32x2 x = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, plane2));
+}
+
+// hi/lo split of two values at once: x ~= hi + lo with hi = plane(x), lo = plane(x - hi); both planes come out as
+// packed dwords (2 packed conversions + 2 widening conversions + one packed subtract for the pair, against ~15
+// scalar instructions for two split_h16 calls: the plane-writing epilogues were VALU-heavy)
+__device__ __forceinline__ void split2_h16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2 x = {a, b};
+  const plane2 h = __builtin_convertvector(x, plane2);
+  const f32x2 r = x - __builtin_convertvector(h, f32x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, plane2));
+}
+
+// hi/lo split of one value
 __device__ __forceinline__ void split_h16(float x, h16_t& hi, h16_t& lo) {
   hi = f2h(x);
   lo = f2h(x - h2f(hi));
@@ -65,6 +80,24 @@ __device__ __forceinline__ void split_h16(float x, h16_t& hi, h16_t& lo) {
 __device__ __forceinline__ uint32_t pack2(h16_t a, h16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }
+
+// Range check of the values a thread converts to half planes: running max of |x| (one v_max3_f32 per two values),
+// ONE compare at the end; a thread that saw |x| > 65504 stores `tag` (which kernel class: msd_api.hip) to the
+// handle's flag word.  Compiles to nothing in the bfloat16-plane build (float32's exponent range).
+struct RangeCheck {
+  float m = 0.f;
+  __device__ __forceinline__ void see(float a, float b) {
+    if constexpr (kPlaneSaturates) asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+  }
+  __device__ __forceinline__ void see(float a) {
+    if constexpr (kPlaneSaturates) asm("v_max_f32 %0, %0, |%1|" : "+v"(m) : "v"(a));
+  }
+  __device__ __forceinline__ void commit(unsigned* flag, unsigned tag) const {
+    if constexpr (kPlaneSaturates) {
+      if (flag != nullptr && !(m <= kPlaneMax)) *flag = tag;
+    }
+  }
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

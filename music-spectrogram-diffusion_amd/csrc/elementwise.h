@@ -23,6 +23,8 @@ struct NormParams {
   int rows, D;
   h16_t* out[2];
   float* out_f32;
+  unsigned* sat = nullptr;   // half-plane range flag (common.h RangeCheck)
+  unsigned sat_tag = 1;
 };
 
 template <int OUT, int VPL>  // VPL = float4 loads per lane: D <= 256*VPL
@@ -45,6 +47,7 @@ __global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
   const float rstd = 1.0f / sqrtf(ss / (float)p.D + 1e-6f);
   const float* fs = nullptr;
   if (p.film) fs = p.film + ((size_t)(*p.step_ptr) * p.film_slots + p.film_slot) * (2 * p.D);
+  RangeCheck rc;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (lane + i * 64) * 4;
@@ -63,18 +66,19 @@ __global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
       if (OUT == 2) {
         *reinterpret_cast<float4*>(p.out_f32 + off) = make_float4(y[0], y[1], y[2], y[3]);
       } else {
-        h16_t h[4], l[4];
+        uint32_t h[2], l[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (OUT == 1) split_h16(y[e], h[e], l[e]);
-          else h[e] = f2h(y[e]);
+        for (int e = 0; e < 2; ++e) {
+          rc.see(y[2 * e], y[2 * e + 1]);
+          if (OUT == 1) split2_h16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+          else h[e] = cvt2_h16(y[2 * e], y[2 * e + 1]);
         }
-        *reinterpret_cast<uint2*>(p.out[0] + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-        if (OUT == 1)
-          *reinterpret_cast<uint2*>(p.out[1] + off) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+        *reinterpret_cast<uint2*>(p.out[0] + off) = make_uint2(h[0], h[1]);
+        if (OUT == 1) *reinterpret_cast<uint2*>(p.out[1] + off) = make_uint2(l[0], l[1]);
       }
     }
   }
+  rc.commit(p.sat, p.sat_tag);
 }
 
 // ---------------------------------------------------------------------------
@@ -106,8 +110,10 @@ struct SamplerParams {
   float cond_wt;        // eval_condition_weight
   int clip_x0, ddim;
   int model_output = kOutEps;   // what the network predicts (diffusion_utils.py:288-322)
-  h16_t* z_hi;         // optional bf16 planes of the new z (A operand of the next input projection)
+  h16_t* z_hi;         // optional 16-bit planes of the new z (A operand of the next input projection)
   h16_t* z_lo;
+  unsigned* sat = nullptr;   // half-plane range flag (common.h RangeCheck)
+  unsigned sat_tag = 1;
 };
 
 // model output -> (eps, x0) at the TRAIN schedule's log-SNR (diffusion_utils.py:288-322)
@@ -166,11 +172,16 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
     for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zin[k], e0[k], e1[k], nn[k]);
     *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
     if (p.z_hi) {
-      h16_t h[4], l[4];
+      uint32_t h[2], l[2];
+      RangeCheck rc;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) split_h16(out[k], h[k], l[k]);
-      *reinterpret_cast<uint2*>(p.z_hi + idx) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-      if (p.z_lo) *reinterpret_cast<uint2*>(p.z_lo + idx) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+      for (int k = 0; k < 2; ++k) {
+        rc.see(out[2 * k], out[2 * k + 1]);
+        split2_h16(out[2 * k], out[2 * k + 1], h[k], l[k]);
+      }
+      *reinterpret_cast<uint2*>(p.z_hi + idx) = make_uint2(h[0], h[1]);
+      if (p.z_lo) *reinterpret_cast<uint2*>(p.z_lo + idx) = make_uint2(l[0], l[1]);
+      rc.commit(p.sat, p.sat_tag);
     }
   }
   // every block has read *step_ptr before any kernel of the next step can start
@@ -180,7 +191,7 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
 }
 
 // g[step][slot][k] = gamma[k] * (film_scale[step][slot][k] + 1): the column multiplier of a
-// FiLM-modulated RMSNorm, tabulated for every step (folded-norm GEMM epilogues, gemm_bf16.h)
+// FiLM-modulated RMSNorm, tabulated for every step (folded-norm GEMM epilogues, gemm_h16.h)
 __global__ void build_g_kernel(const float* film, const float* gamma, float* g, int n_steps, int slots,
                                int slot, int D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -301,13 +312,17 @@ __global__ void philox_normal_kernel(float* out, int64_t n, uint32_t seed_lo, ui
 }
 
 // fp32 -> bf16 planes (test helper for the standalone ops)
-__global__ void split_planes_kernel(const float* in, h16_t* hi, h16_t* lo, int64_t n) {
+__global__ void split_planes_kernel(const float* in, h16_t* hi, h16_t* lo, int64_t n, unsigned* sat = nullptr,
+                                    unsigned sat_tag = 1) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     h16_t h, l;
+    RangeCheck rc;
+    rc.see(in[i]);
     split_h16(in[i], h, l);
     hi[i] = h;
     if (lo) lo[i] = l;
+    rc.commit(sat, sat_tag);
   }
 }
 __global__ void merge_planes_kernel(const h16_t* hi, const h16_t* lo, float* out, int64_t n) {

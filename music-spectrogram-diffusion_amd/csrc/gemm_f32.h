@@ -33,7 +33,7 @@ struct EpiF32Swish {  // nn.swish (network.py:385,391)
   }
 };
 // out[m][packed(n)] = v, packed(n) = (n/16)*32 + which*16 + n%16: the wi_0/wi_1 column
-// interleave of the gated-MLP weight (gemm_bf16.h EpiGeglu), for the folded FiLM-bias table
+// interleave of the gated-MLP weight (gemm_h16.h EpiGeglu), for the folded FiLM-bias table
 struct EpiF32StoreGated {
   float* out;
   int ldc, which;

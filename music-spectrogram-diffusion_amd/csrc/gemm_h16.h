@@ -1,10 +1,11 @@
-// bf16 / bf16x3 MFMA GEMM for the small-M (M = 256..2304) transformer projections.
+// 16-bit-plane MFMA GEMM ("h16": IEEE-half planes in libmsd_amd.so, bfloat16 planes in libmsd_amd_bf16.so --
+// common.h) for the small-M (M = 256..2304) transformer projections.
 //
-//   C[M,N] (+)= A[M,K] . W[K,N]        A: bf16 planes [M,K] row-major
+//   C[M,N] (+)= A[M,K] . W[K,N]        A: 16-bit planes [M,K] row-major
 //                                      W: packed at load time as W^T planes [N,K]
-// NP = 1: plain bf16 operands.  NP = 2 ("bf16x3"): A = Ah+Al, W = Wh+Wl and the
-// product is Ah.Wh + Ah.Wl + Al.Wh (three v_mfma_f32_16x16x32_bf16 per tile),
-// fp32 accumulate: fp32-class accuracy at the bf16 MFMA rate / 3.
+// NP = 1: one plane per operand.  NP = 2 ("f16x3" / "bf16x3"): A = Ah+Al, W = Wh+Wl and the
+// product is Ah.Wh + Ah.Wl + Al.Wh (three v_mfma_f32_16x16x32_f16 per tile),
+// fp32 accumulate: fp32-class accuracy at the 16-bit MFMA rate / 3.
 //
 // What bounds this kernel on MI355X (profiles/r01_*): with M = 256..512 every
 // operand is L2-resident or streamed once, and the limiter is the per-CU vector
@@ -122,6 +123,14 @@ struct GemmParams {
   WeightPrefetch pf;  // optional: warm a later launch's weights (see WeightPrefetch)
   int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
+  unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
+  unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
+};
+
+// where an epilogue reports an activation that left the half-plane range
+struct SatFlag {
+  unsigned* p = nullptr;
+  unsigned tag = 1;
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem mfma_h16x8;
@@ -155,7 +164,7 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 
 // ----------------------------------------------------------------------------
 // LDS-DMA ("global_load_lds") staging.  Ablation of an earlier register-staged kernel
-// (kept for the micro-benchmarks only: tools/ubench/gemm_bf16_regstaged.h, MSD_ABL=4)
+// (kept for the micro-benchmarks only: tools/ubench/gemm_h16_regstaged.h, MSD_ABL=4)
 // showed ~45 % of its time in the ds_write pass (ds_write_b128 sustains only ~79 B/clk/CU and sits in front of the
 // MFMAs in every wave).  Here the memory pipeline writes the tiles into LDS itself:
 // no staging VGPRs, no ds_write, NS-deep LDS ring, one raw s_barrier per K-tile and a
@@ -165,7 +174,7 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // applied to the per-lane SOURCE address (lane (r, c') fetches global chunk c' ^ r).
 // ----------------------------------------------------------------------------
 // One output tile (bm, bn) by the 256 threads of the calling block; `smem` = the block's dynamic LDS
-// (gemm_bf16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
+// (gemm_h16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
 // kernel may have produced (A planes, residual tile, row statistics): 0 in the stand-alone kernel, 16 (sc1:
 // bypass the CU's L1, served by the XCD's L2) inside the XCD-resident chain kernels (chain.h).
 template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone>
@@ -401,12 +410,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
                       acc[i][j][3] * kWScaleInv);   // weights are packed times kWScale (common.h)
   epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
   __syncthreads();
-  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true);
+  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
   prefetch_done(pf_keep);
 }
 
 template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
-__global__ void __launch_bounds__(256) gemm_bf16_dma_kernel(GemmParams p, Epi epi) {
+__global__ void __launch_bounds__(256) gemm_h16_dma_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
   // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
@@ -440,20 +449,13 @@ __device__ __forceinline__ void tile_row8(const float* s0, int m, int n, float v
 }
 
 template <int NP>
-__device__ __forceinline__ void store_h16x8(h16_t* const* planes, size_t off, const float v[8]) {
+__device__ __forceinline__ void store_h16x8(h16_t* const* planes, size_t off, const float v[8], RangeCheck& rc) {
   uint32_t wh[4], wl[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    h16_t h0, l0, h1, l1;
-    if (NP == 2) {
-      split_h16(v[2 * e], h0, l0);
-      split_h16(v[2 * e + 1], h1, l1);
-      wl[e] = pack2(l0, l1);
-    } else {
-      h0 = f2h(v[2 * e]);
-      h1 = f2h(v[2 * e + 1]);
-    }
-    wh[e] = pack2(h0, h1);
+    rc.see(v[2 * e], v[2 * e + 1]);
+    if (NP == 2) split2_h16(v[2 * e], v[2 * e + 1], wh[e], wl[e]);
+    else wh[e] = cvt2_h16(v[2 * e], v[2 * e + 1]);
   }
   *reinterpret_cast<uint4*>(planes[0] + off) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
   if (NP == 2) *reinterpret_cast<uint4*>(planes[1] + off) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
@@ -567,7 +569,7 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
 
 // C (row-major bf16 planes) = acc [* rstd[m] + bias[n]]
 template <int NP>
-struct EpiStoreBf16 {
+struct EpiStoreH16 {
   h16_t* out[2];
   int ldc;
   RowScale rsc;
@@ -581,10 +583,12 @@ struct EpiStoreBf16 {
     if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
+    RangeCheck rc;
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -593,8 +597,9 @@ struct EpiStoreBf16 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
       }
-      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v);
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
     }
+    rc.commit(sf.p, sf.tag);
   }
 };
 
@@ -617,10 +622,12 @@ struct EpiQKV {
     if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
+    RangeCheck rc;
     if (n0 < v_start) {
       for (int item = tid; item < BM * BN / 8; item += 256) {
         const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
@@ -630,7 +637,7 @@ struct EpiQKV {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
         }
-        store_h16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v);
+        store_h16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v, rc);
       }
     } else {
       // transposed items: (column n, 8 consecutive rows = keys).  Keys o..o+7 of a
@@ -653,18 +660,19 @@ struct EpiQKV {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int kp = vt_perm16((key & 15) + 4 * hh);
-          h16_t h[4], l[4];
+          uint32_t h[2], l[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (NP == 2) split_h16(v[4 * hh + e], h[e], l[e]);
-            else h[e] = f2h(v[4 * hh + e]);
+          for (int e = 0; e < 2; ++e) {
+            rc.see(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1]);
+            if (NP == 2) split2_h16(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1], h[e], l[e]);
+            else h[e] = cvt2_h16(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1]);
           }
-          *reinterpret_cast<uint2*>(base[0] + kp) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-          if (NP == 2)
-            *reinterpret_cast<uint2*>(base[1] + kp) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+          *reinterpret_cast<uint2*>(base[0] + kp) = make_uint2(h[0], h[1]);
+          if (NP == 2) *reinterpret_cast<uint2*>(base[1] + kp) = make_uint2(l[0], l[1]);
         }
       }
     }
+    rc.commit(sf.p, sf.tag);
   }
 };
 
@@ -678,7 +686,8 @@ struct EpiResidual {
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -724,10 +733,12 @@ struct EpiResidualNorm {
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
     const bool pre = aux && BN == 32;
     const int step = pre ? 0 : *step_ptr;
+    RangeCheck rc;
     // one tile-element group (8 columns of one row); LX / LG fetch the residual and the gain
     auto body = [&](int item, auto LX, auto LG) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;   // BN/8 consecutive lanes share a row
@@ -753,7 +764,7 @@ struct EpiResidualNorm {
         LG(lo_rows, n, col, g0, g1);
         v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
         v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
-        store_h16x8<NP>(y, (size_t)row * ldx + col, v);
+        store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
       }
     };
     if (pre) {   // operands prefetched into the aux LDS region: explicit LDS pointers (ds_read)
@@ -780,6 +791,7 @@ struct EpiResidualNorm {
                g1 = *reinterpret_cast<const float4*>(g + col + 4);
              });
     }
+    rc.commit(sf.p, sf.tag);
   }
 };
 
@@ -804,13 +816,15 @@ struct EpiInProj {
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     static_assert(BN == 64 || BN == 32, "partial sums of squares are per BN-column tile");
     const int step = *step_ptr;
     // first kernel of the DDPM step: publish the index in slot 1 for the sampler (elementwise.h),
     // which then owns slot 0 and decrements it without a separate launch
     if (step_copy && m0 == 0 && n0 == 0 && tid == 0) step_copy[1] = step;
     const float* gs = g + (size_t)step * g_stride;
+    RangeCheck rc;
     for (int item = tid; item < BM * BN / 8; item += 256) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
       float v[8];
@@ -836,9 +850,10 @@ struct EpiInProj {
         px[0] = make_float4(v[0], v[1], v[2], v[3]);
         px[1] = make_float4(v[4], v[5], v[6], v[7]);
         if ((item % (BN / 8)) == 0) ssq[r * tiles + n0 / BN] = sq;
-        store_h16x8<NP>(y, r * ldx + col, w);
+        store_h16x8<NP>(y, r * ldx + col, w, rc);
       }
     }
+    rc.commit(sf.p, sf.tag);
   }
 };
 
@@ -857,7 +872,8 @@ struct EpiStoreF32 {
     if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     float* rs = s0 + BM * LD;
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
@@ -895,12 +911,14 @@ struct EpiGeglu {
     if (rsc.ssq) tile_rstd_compute<BM>(rsc, s0 + BM * LD, m0, tid, aux);
   }
   template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false) const {
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
     static_assert(BN % 32 == 0, "gated epilogue needs whole wi_0/wi_1 groups");
     constexpr int OUT_N = BN / 2;  // output columns per tile
     float* rs = s0 + BM * LD;
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
+    RangeCheck rc;
     for (int item = tid; item < BM * OUT_N / 8; item += 256) {
       const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
       const int pc = (j / 16) * 32 + (j % 16);
@@ -916,44 +934,45 @@ struct EpiGeglu {
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
-      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v);
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v, rc);
     }
+    rc.commit(sf.p, sf.tag);
   }
 };
 
 template <int NP, int BM, int BN, int NS, class Epi>
-constexpr int gemm_bf16_dma_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN>(); }
+constexpr int gemm_h16_dma_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN>(); }
 
 template <int NP, int BM, int BN, int NS, class Epi, int PF>
-inline hipError_t gemm_bf16_dma_prepare_one() {
-  constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
+inline hipError_t gemm_h16_dma_prepare_one() {
+  constexpr int smem = gemm_h16_dma_smem<NP, BM, BN, NS, Epi>();
   if (smem < 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PF>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 // one-time opt-in to > 64 KiB dynamic LDS; call for every instantiation OUTSIDE stream capture
 template <int NP, int BM, int BN, int NS, class Epi>
-inline hipError_t gemm_bf16_dma_prepare() {
-  hipError_t e = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 0>(), r;
+inline hipError_t gemm_h16_dma_prepare() {
+  hipError_t e = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 0>(), r;
   if constexpr (NP == 2) {   // the single-plane mode never prefetches
-    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 1>()) != hipSuccess) e = r;
-    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 2>()) != hipSuccess) e = r;
-    if ((r = gemm_bf16_dma_prepare_one<NP, BM, BN, NS, Epi, 3>()) != hipSuccess) e = r;
+    if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 1>()) != hipSuccess) e = r;
+    if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 2>()) != hipSuccess) e = r;
+    if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 3>()) != hipSuccess) e = r;
   }
   return e;
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>
-inline hipError_t launch_gemm_bf16_dma(const GemmParams& p, const Epi& epi, hipStream_t stream) {
-  constexpr int smem = gemm_bf16_dma_smem<NP, BM, BN, NS, Epi>();
-  static const hipError_t attr = gemm_bf16_dma_prepare<NP, BM, BN, NS, Epi>();
+inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipStream_t stream) {
+  constexpr int smem = gemm_h16_dma_smem<NP, BM, BN, NS, Epi>();
+  static const hipError_t attr = gemm_h16_dma_prepare<NP, BM, BN, NS, Epi>();
   if (attr != hipSuccess) return attr;
   const int rx = p.xcd_rows, cx = 8 / rx;
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
   // one kernel instantiation per number of prefetch targets (single path: see prefetch_weights)
 #define MSD_LAUNCH_PF(PF_) \
-  hipLaunchKernelGGL((gemm_bf16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256), smem, stream, p, epi)
+  hipLaunchKernelGGL((gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256), smem, stream, p, epi)
   const int npf = NP == 2 ? prefetch_kind(p.pf) : 0;
   if constexpr (NP == 2) {
     if (npf == 1) MSD_LAUNCH_PF(1);

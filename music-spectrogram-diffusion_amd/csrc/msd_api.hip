@@ -19,7 +19,7 @@
 #include "chain.h"
 #include "common.h"
 #include "elementwise.h"
-#include "gemm_bf16.h"
+#include "gemm_h16.h"
 #include "gemm_f32.h"
 
 using namespace msd;
@@ -111,7 +111,7 @@ struct msd_model {
   float* d_coef = nullptr;  // [N][kCoefCount]
   std::vector<float> h_coef;
   float* d_film = nullptr;  // [N][2*Ld][2D]
-  // folded-norm tables (gemm_bf16.h): g = gamma (.) (film_scale + 1); b.W per step
+  // folded-norm tables (gemm_h16.h): g = gamma (.) (film_scale + 1); b.W per step
   float* d_g = nullptr;        // [N][2*Ld][D]
   float* d_bw_self = nullptr;  // [N][Ld][3J]   film_bias_self . (Wq|Wk|Wv)
   float* d_bw_mlp = nullptr;   // [N][Ld][2F]   film_bias_mlp  . (wi_0|wi_1), packed column order
@@ -163,6 +163,8 @@ struct msd_model {
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
+  unsigned* d_sat = nullptr;   // half-plane range flag: kernel class + 1 of a conversion that saw |x| > 65504 (common.h RangeCheck)
+  unsigned* h_sat = nullptr;   // pinned host copy, read after the stream sync that ends msd_encode / msd_sample
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
   Profiler prof;
 };
@@ -208,6 +210,27 @@ int palloc(msd_model* m, Planes* pl, size_t count) {
 }
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// Half-plane range flag (common.h RangeCheck): read it behind a stream sync; a set flag fails the call LOUDLY
+// (round 2 clamped at 65504 and returned MSD_OK with a wrong spectrogram).  The flag is cleared for the next call.
+int check_range(msd_model* m, hipStream_t s, const char* what) {
+  if (!kPlaneSaturates) {
+    HIP_TRY(m, hipStreamSynchronize(s));
+    return MSD_OK;
+  }
+  HIP_TRY(m, hipMemcpyAsync(m->h_sat, m->d_sat, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  const unsigned tag = *m->h_sat;
+  if (tag == 0) return MSD_OK;
+  HIP_TRY(m, hipMemsetAsync(m->d_sat, 0, sizeof(unsigned), s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  const char* cls = (tag >= 1 && tag <= (unsigned)KC_COUNT) ? kClassNames[tag - 1] : "?";
+  return fail(m, MSD_ERR_RANGE,
+              "%s: an activation left the range of the IEEE-half operand planes (|x| > %g) in kernel class '%s'; the "
+              "result of this call is INVALID.  Use precision 'bf16x3' (libmsd_amd_bf16.so: bfloat16 planes keep "
+              "float32's exponent range at twice the rounding error)", what, (double)kPlaneMax, cls);
+}
+
 
 void add_weight(msd_model* m, const std::string& name, int64_t a, int64_t b = -1) {
   Weight w;
@@ -306,7 +329,7 @@ GemmParams gp(const Planes& a, int lda, const Planes& b, int ldb, int M, int N, 
   return p;
 }
 
-// Kernel selection (gemm_bf16.h).  The LDS-DMA variant everywhere; tile shapes from
+// Kernel selection (gemm_h16.h).  The LDS-DMA variant everywhere; tile shapes from
 // tools/ubench/gemm_bench.hip run with COLD weights (48 rotating copies), which is what a DDPM
 // step sees: every weight matrix is touched once per ~1.4 ms and comes from HBM, so the ring
 // depth has to cover HBM latency, not L2 latency.  bf16x3, M = 512, us warm -> cold:
@@ -326,7 +349,8 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.begin(kc);
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   if (pf) p.pf = *pf;
-  // XCD grid (gemm_bf16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  // XCD grid (gemm_h16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
   // (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
   // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
   // better than 1 x 8 everywhere.
@@ -346,7 +370,7 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
     p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
     p.xcd_walk_n = walk_n;
   }
-  hipError_t e = launch_gemm_bf16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
+  hipError_t e = launch_gemm_h16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
@@ -427,7 +451,7 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 #undef MSD_GO
 }
 
-// Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_bf16.h PrefetchTarget)
+// Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_h16.h PrefetchTarget)
 template <int NP>
 PrefetchTarget weights_target(const msd_model* m, const Planes& w, int N, int K) {
   PrefetchTarget t;
@@ -444,14 +468,14 @@ WeightPrefetch prefetch_of(const msd_model* m, const Planes& w, int N, int K) {
 template <int NP>
 hipError_t prepare_gemms() {
   hipError_t e = hipSuccess, r;
-#define PREP(BM, BN, NS, EPI) if ((r = gemm_bf16_dma_prepare<NP, BM, BN, NS, EPI>()) != hipSuccess) e = r;
+#define PREP(BM, BN, NS, EPI) if ((r = gemm_h16_dma_prepare<NP, BM, BN, NS, EPI>()) != hipSuccess) e = r;
   PREP(64, 64, wide_ns(NP), EpiQKV<NP>) PREP(64, 64, wide_ns(NP), EpiGeglu<NP>)
   if constexpr (NP == 2) {
     PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiQKV<NP>) PREP(128, 128, 2, EpiGeglu<NP>)
-    PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreBf16<NP>)
+    PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreH16<NP>)
   }
-  PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreBf16<NP>)
+  PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreH16<NP>)
   PREP(32, 32, 4, EpiStoreF32) PREP(32, 32, 4, EpiInProj<NP>)
   PREP(64, 32, kTallNS, EpiResidual) PREP(64, 32, kTallNS, EpiResidualNorm<NP>)
   PREP(64, 64, 3, EpiStoreF32)
@@ -468,6 +492,7 @@ void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const flo
   p.out[0] = out ? out->p[0] : nullptr;
   p.out[1] = out ? out->p[NP - 1] : nullptr;
   p.out_f32 = out_f32;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)KC_NORM + 1u;
   const dim3 grid((rows + 3) / 4), block(256);
   c.begin(KC_NORM);
   const int vpl = (D + 255) / 256;
@@ -499,6 +524,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   p.ksplit = ksplit; p.part_o = c.m->att_part_o; p.part_ml = c.m->att_part_ml;
   p.total_rows = q_rows_per_seg * segs;
   if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -858,9 +884,11 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
   }
   HIP_TRY(m, hipMemcpyAsync(m->d_nkeys_cross, m->h_nkeys_cross.data(), m->h_nkeys_cross.size() * sizeof(int),
                             hipMemcpyHostToDevice, s));
-  HIP_TRY(m, hipStreamSynchronize(s));
-  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "encode failed: %s", hipGetErrorString(c.err));
-  return MSD_OK;
+  if (c.err != hipSuccess) {
+    (void)hipStreamSynchronize(s);
+    return fail(m, MSD_ERR_HIP, "encode failed: %s", hipGetErrorString(c.err));
+  }
+  return check_range(m, s, "msd_encode");   // synchronises
 }
 
 // ---- one decoder evaluation (network.py:360-457) on rows [0, P*batch*T) ----------
@@ -886,7 +914,7 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
     gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
     if (cond0) {
       norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
-      EpiStoreBf16<NP> es;
+      EpiStoreH16<NP> es;
       es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
       gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross[0], D, BT, J, D, es);
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
@@ -963,7 +991,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
     // through one norm kernel; later layers consume the folded-norm planes `y` written by the
     // previous layer's MLP output projection (inside that layer's chain launch when chains are on).
-    // Weight prefetch plan of a layer (gemm_bf16.h WeightPrefetch; every producer warms a LATER GEMM's weights
+    // Weight prefetch plan of a layer (gemm_h16.h WeightPrefetch; every producer warms a LATER GEMM's weights
     // behind its own epilogue): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional
     // pass) . cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
     const bool last_layer = (l + 1 == m->Ld);
@@ -994,7 +1022,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
       for (int e = 0; e < m->n_cross; ++e) {
         const Planes& cq = e == 0 ? m->cq : m->cq2;
-        EpiStoreBf16<NP> es;
+        EpiStoreH16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
         es.rsc = rowscale(nullptr, 0);
         const WeightPrefetch pf = prefetch_of<NP>(m, w.wo_cross[e], D, J);
@@ -1100,7 +1128,7 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
 void split_z(msd_model* m, int64_t n, hipStream_t s) {
   if (!m->fold_norm) return;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, m->zp.p[0],
-                     m->NP == 2 ? m->zp.p[1] : (h16_t*)nullptr, n);
+                     m->NP == 2 ? m->zp.p[1] : (h16_t*)nullptr, n, m->d_sat, (unsigned)KC_SAMPLER + 1u);
 }
 
 template <int NP>
@@ -1131,6 +1159,7 @@ void enqueue_step(Ctx& c, int batch) {
   sp.model_output = m->cfg.model_output;
   sp.z_hi = m->fold_norm ? m->zp.p[0] : nullptr;
   sp.z_lo = (m->fold_norm && m->NP == 2) ? m->zp.p[1] : nullptr;
+  sp.sat = m->d_sat; sp.sat_tag = (unsigned)KC_SAMPLER + 1u;
   c.begin(KC_SAMPLER);
   sp.step_from_slot1 = m->fold_norm ? 1 : 0;
   hipLaunchKernelGGL(sampler_step_kernel, dim3((sp.n / 4 + 255) / 256), dim3(256), 0, c.s, sp);
@@ -1181,7 +1210,17 @@ int msd_create(const msd_config* cfg, msd_model** out) {
     return MSD_ERR_INVALID_ARGUMENT;
   };
   if (cfg->head_dim != kHeadDim) { m->err = "head_dim must be 64"; *out = m; return MSD_ERR_UNSUPPORTED; }
-  if (cfg->precision != MSD_PREC_BF16 && cfg->precision != MSD_PREC_BF16X3) return bad("unknown precision");
+  if (cfg->precision < MSD_PREC_F16 || cfg->precision > MSD_PREC_BF16X3) return bad("unknown precision");
+  {  // the plane FORMAT is a property of the library build (common.h): refuse the other build's precisions
+    const bool want_bf16 = cfg->precision == MSD_PREC_BF16 || cfg->precision == MSD_PREC_BF16X3;
+    if (want_bf16 != (MSD_PLANE_BF16 != 0)) {
+      m->err = std::string("this library holds operand planes in ") + (MSD_PLANE_BF16 ? "bfloat16" : "IEEE half") +
+               (MSD_PLANE_BF16 ? ": it implements MSD_PREC_BF16 / MSD_PREC_BF16X3; load libmsd_amd.so for MSD_PREC_F16 / MSD_PREC_F16X3"
+                               : ": it implements MSD_PREC_F16 / MSD_PREC_F16X3; load libmsd_amd_bf16.so for MSD_PREC_BF16 / MSD_PREC_BF16X3");
+      *out = m;
+      return MSD_ERR_UNSUPPORTED;
+    }
+  }
   if (cfg->sampler != MSD_SAMPLER_DDPM && cfg->sampler != MSD_SAMPLER_DDIM) return bad("Unknown sampler type");
   if (cfg->emb_dim % 64 || cfg->emb_dim > 1024 || cfg->emb_dim < 64) return bad("emb_dim must be a multiple of 64 in [64, 1024]");
   if (cfg->mlp_dim % 64) return bad("mlp_dim must be a multiple of 64");
@@ -1194,7 +1233,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
     std::string why;
     if (!build_coef_rows(*cfg, &rows, &why)) { m->err = why; *out = m; return MSD_ERR_INVALID_ARGUMENT; }
   }
-  m->NP = cfg->precision == MSD_PREC_BF16X3 ? 2 : 1;
+  m->NP = (cfg->precision == MSD_PREC_F16X3 || cfg->precision == MSD_PREC_BF16X3) ? 2 : 1;
   m->D = cfg->emb_dim; m->H = cfg->num_heads; m->J = cfg->num_heads * kHeadDim; m->F = cfg->mlp_dim;
   m->T = cfg->targets_length; m->L = cfg->inputs_length; m->C = cfg->has_context ? cfg->context_length : 0;
   m->ND = cfg->n_dims; m->N = cfg->num_steps; m->Ld = cfg->num_decoder_layers; m->Le = cfg->num_encoder_layers;
@@ -1215,7 +1254,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
     // L2 (the 2 x 4 XCD grid of the stand-alone GEMMs shares each weight tile between 4 row tiles), which costs
     // what the two saved kernel boundaries win.  MSD_CHAIN=1 turns it on (parity-tested, tests/test_gpu_model.py).
     const char* v = getenv("MSD_CHAIN");
-    m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && cfg->precision == MSD_PREC_BF16X3 && m->cus >= 8 &&
+    m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && m->NP == 2 && m->cus >= 8 &&
                    m->cus % 8 == 0 && (2 * cfg->mlp_dim) % 128 == 0 && cfg->emb_dim % 32 == 0 &&
                    (3 * cfg->num_heads * kHeadDim) % 64 == 0;
   }
@@ -1267,6 +1306,9 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
   TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_absmax, 1));
+  TRY(dalloc(m, &m->d_sat, 1));
+  HIP_TRY(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_sat), sizeof(unsigned), hipHostMallocDefault));
+  *m->h_sat = 0;
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
   TRY(dalloc(m, &m->d_nkeys_cross, (size_t)2 * m->Bmax));
   m->h_nkeys_cross.assign((size_t)m->n_cross * m->Bmax, 0);
@@ -1312,6 +1354,7 @@ void msd_destroy(msd_model* m) {
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->noise_own) (void)hipFree(m->noise_own);
+  if (m->h_sat) (void)hipHostFree(m->h_sat);
   for (void* p : m->allocs) (void)hipFree(p);
   delete m;
 }
@@ -1495,12 +1538,11 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
-  HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
-  if (m->chain_mlp) {   // a timed-out XCD barrier of an earlier call (chain.h) must not go unnoticed
-    int bad = 0;
-    HIP_TRY(m, hipMemcpy(&bad, m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (bad) return fail(m, MSD_ERR_HIP, "an XCD-resident chain kernel timed out at a barrier (%d): set MSD_CHAIN=0", bad);
+  if (m->chain_mlp) {   // chain.h: fresh barrier counters for every call (the arrival index would wrap after ~1e8 barriers)
+    HIP_TRY(m, hipMemsetAsync(m->d_bar, 0, sizeof(unsigned) * 8 * kBarStride, s));
+    HIP_TRY(m, hipMemsetAsync(m->d_chain_err, 0, sizeof(int), s));
   }
+  HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
 
   // One graph = `graph_steps` consecutive DDPM steps (the scan index lives in device memory, so
   // the same graph serves every position); a second, single-step graph covers N mod graph_steps.
@@ -1538,7 +1580,15 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, out_dev,
                      (int)n, m->cfg.feature_min, m->cfg.feature_max);
   HIP_TRY(m, hipGetLastError());
-  if (null_stream) HIP_TRY(m, hipStreamSynchronize(s));
+  // The call ends with ONE stream synchronisation (tens of microseconds against a ~1 s segment): behind it the
+  // half-plane range flag and the chain kernels' barrier flag are read, so that a bad run fails THIS call.
+  const int rc = check_range(m, s, "msd_sample");
+  if (rc) return rc;
+  if (m->chain_mlp) {
+    int bad = 0;
+    HIP_TRY(m, hipMemcpy(&bad, m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) return fail(m, MSD_ERR_HIP, "an XCD-resident chain kernel timed out at a barrier (%d times): the result of this call is invalid; set MSD_CHAIN=0", bad);
+  }
   return MSD_OK;
 }
 
@@ -1570,7 +1620,7 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   else { in_proj<1>(c, batch, 1); decoder_layers<1>(c, batch, 1, include_conditioning != 0); }
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "decoder pass failed: %s", hipGetErrorString(c.err));
   HIP_TRY(m, hipMemcpyAsync(eps_out_dev, m->eps, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return MSD_OK;
+  return check_range(m, s, "msd_decoder_pass");   // synchronises
 }
 
 int msd_get_schedule(const msd_model* m, float* host_out) {
@@ -1678,33 +1728,70 @@ struct Scratch {
     return static_cast<Tp*>(q);
   }
 };
-void split(const float* in, h16_t* hi, h16_t* lo, int64_t n, hipStream_t s) {
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, hi, lo, n);
+// Range bookkeeping of a stand-alone op: device words [0] = bits of the largest packed |w| (pack_wt_kernel),
+// [1] = the activation range flag (common.h RangeCheck).  The ops fail like the model does: weights beyond the
+// half-plane range -> MSD_ERR_UNSUPPORTED (msd_finalize_weights), activations beyond it -> MSD_ERR_RANGE.
+struct OpFlags {
+  unsigned* d = nullptr;
+  bool init(Scratch& sc) { d = sc.get<unsigned>(2); return d != nullptr; }
+  unsigned* absmax() const { return d; }
+  unsigned* sat() const { return d + 1; }
+  template <class P> void arm(P& p) const { p.sat = sat(); p.sat_tag = 1; }
+  int finish(hipStream_t s) const {   // synchronises
+    unsigned h[2] = {0, 0};
+    if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return MSD_ERR_HIP;
+    if (kPlaneSaturates) {
+      float top;
+      memcpy(&top, &h[0], sizeof(top));
+      if (!(top < kPlaneMax / kWScale)) return MSD_ERR_UNSUPPORTED;
+      if (h[1]) return MSD_ERR_RANGE;
+    }
+    return MSD_OK;
+  }
+};
+// planes per operand of an op's `precision` argument; -1: not a precision of THIS build's plane format
+int op_planes(int precision) {
+  const bool bf = precision == MSD_PREC_BF16 || precision == MSD_PREC_BF16X3;
+  if (precision < MSD_PREC_F16 || precision > MSD_PREC_BF16X3 || bf != (MSD_PLANE_BF16 != 0)) return -1;
+  return (precision == MSD_PREC_F16X3 || precision == MSD_PREC_BF16X3) ? 2 : 1;
+}
+void split(const float* in, h16_t* hi, h16_t* lo, int64_t n, hipStream_t s, unsigned* sat = nullptr) {
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, hi, lo, n, sat, 1u);
 }
 }  // namespace
 }  // extern "C++"
 
-int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev, int M,
-                     int N, int K, void* stream) {
+int msd_op_gemm_h16(int precision, const float* a_dev, const float* w_dev, float* c_dev, int M,
+                    int N, int K, void* stream) {
   if (M % 64 || N % 64 || K % 64 || M <= 0 || N <= 0 || K <= 0) return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int NP = precision == MSD_PREC_BF16X3 ? 2 : 1;
+  const int NP = op_planes(precision);
+  if (NP < 0) return MSD_ERR_UNSUPPORTED;
   Scratch sc;
+  OpFlags fl;
+  if (!fl.init(sc)) return MSD_ERR_HIP;
   Planes a, w;
   for (int i = 0; i < NP; ++i) {
     a.p[i] = sc.get<h16_t>((size_t)M * K);
     w.p[i] = sc.get<h16_t>((size_t)N * K);
     if (!a.p[i] || !w.p[i]) return MSD_ERR_HIP;
   }
-  split(a_dev, a.p[0], NP == 2 ? a.p[1] : nullptr, (int64_t)M * K, s);
+  split(a_dev, a.p[0], NP == 2 ? a.p[1] : nullptr, (int64_t)M * K, s, fl.sat());
   dim3 grid((K + 63) / 64, N), block(64);
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, w.p[0],
-                     NP == 2 ? w.p[1] : (h16_t*)nullptr, 0, 0, 0, (unsigned*)nullptr);
+                     NP == 2 ? w.p[1] : (h16_t*)nullptr, 0, 0, 0, fl.absmax());
   hipError_t e;
-  if (NP == 2) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
-  else e = launch_gemm_bf16_dma<1, 64, 64, 3>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  if (NP == 2) e = launch_gemm_h16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
+  else e = launch_gemm_h16_dma<1, 64, 64, 3>(gp<1>(a, K, w, K, M, N, K), EpiStoreF32{c_dev, N}, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
-  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+  return fl.finish(s);
+}
+
+/* ABI <= 2 name of msd_op_gemm_h16 (the planes were bfloat16 then); kept so that old bindings keep linking */
+int msd_op_gemm_bf16(int precision, const float* a_dev, const float* w_dev, float* c_dev, int M,
+                     int N, int K, void* stream) {
+  return msd_op_gemm_h16(precision, a_dev, w_dev, c_dev, M, N, K, stream);
 }
 
 int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev, int M, int N, int K,
@@ -1723,9 +1810,12 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
       n_keys_valid > n_keys)
     return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int NP = precision == MSD_PREC_BF16X3 ? 2 : 1;
+  const int NP = op_planes(precision);
+  if (NP < 0) return MSD_ERR_UNSUPPORTED;
   const int J = heads * kHeadDim;
   Scratch sc;
+  OpFlags fl;
+  if (!fl.init(sc)) return MSD_ERR_HIP;
   Planes q, k, vt, o;
   int* d_nk = sc.get<int>(1);
   float* vt32 = sc.get<float>((size_t)J * n_keys);
@@ -1738,8 +1828,8 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   }
   if (!d_nk || !vt32) return MSD_ERR_HIP;
   (void)hipMemcpyAsync(d_nk, &n_keys_valid, sizeof(int), hipMemcpyHostToDevice, s);
-  split(q_dev, q.p[0], NP == 2 ? q.p[1] : nullptr, (int64_t)n_q * J, s);
-  split(k_dev, k.p[0], NP == 2 ? k.p[1] : nullptr, (int64_t)n_keys * J, s);
+  split(q_dev, q.p[0], NP == 2 ? q.p[1] : nullptr, (int64_t)n_q * J, s, fl.sat());
+  split(k_dev, k.p[0], NP == 2 ? k.p[1] : nullptr, (int64_t)n_keys * J, s, fl.sat());
   // V -> V^T with the per-16 key permutation, via the GEMM epilogue's own rule (host copy)
   std::vector<float> vh((size_t)n_keys * J), vth((size_t)J * n_keys);
   if (hipMemcpy(vh.data(), v_dev, vh.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return MSD_ERR_HIP;
@@ -1749,8 +1839,9 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
     for (int j = 0; j < J; ++j) vth[(size_t)j * n_keys + kp] = vh[(size_t)key * J + j];
   }
   if (hipMemcpy(vt32, vth.data(), vth.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return MSD_ERR_HIP;
-  split(vt32, vt.p[0], NP == 2 ? vt.p[1] : nullptr, (int64_t)J * n_keys, s);
+  split(vt32, vt.p[0], NP == 2 ? vt.p[1] : nullptr, (int64_t)J * n_keys, s, fl.sat());
   AttnParams p;
+  fl.arm(p);
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
     p.q[i] = q.p[j]; p.k[i] = k.p[j]; p.vt[i] = vt.p[j]; p.o[i] = o.p[j];
@@ -1770,7 +1861,7 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
                      o.p[0], NP == 2 ? o.p[1] : (const h16_t*)nullptr, o_dev, (int64_t)n_q * J);
-  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+  return fl.finish(s);
 }
 
 
@@ -1779,7 +1870,7 @@ extern "C++" {
 namespace {
 // W fp32 [K, N] (reference layout) -> packed W^T planes [N, K]
 bool pack_planes(Scratch& sc, const float* w_dev, int K, int N, int mode, int dst_row0, Planes* out, int rows,
-                 hipStream_t s) {
+                 hipStream_t s, const OpFlags& fl) {
   if (!out->p[0]) {
     out->p[0] = sc.get<h16_t>((size_t)rows * K);
     out->p[1] = sc.get<h16_t>((size_t)rows * K);
@@ -1787,14 +1878,14 @@ bool pack_planes(Scratch& sc, const float* w_dev, int K, int N, int mode, int ds
   }
   dim3 grid((K + 63) / 64, N), block(64);
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w_dev, K, N, out->p[0], out->p[1], dst_row0, mode, 0,
-                     (unsigned*)nullptr);
+                     fl.absmax());
   return hipGetLastError() == hipSuccess;
 }
-bool split_new(Scratch& sc, const float* in, int64_t n, Planes* out, hipStream_t s) {
+bool split_new(Scratch& sc, const float* in, int64_t n, Planes* out, hipStream_t s, const OpFlags& fl) {
   out->p[0] = sc.get<h16_t>((size_t)n);
   out->p[1] = sc.get<h16_t>((size_t)n);
   if (!out->p[0] || !out->p[1]) return false;
-  split(in, out->p[0], out->p[1], n, s);
+  split(in, out->p[0], out->p[1], n, s, fl.sat());
   return true;
 }
 void merge(const Planes& pl, float* out, int64_t n, hipStream_t s) {
@@ -1856,9 +1947,11 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   Scratch sc;
+  OpFlags fl;
+  if (!fl.init(sc)) return MSD_ERR_HIP;
   Planes a, w1, w2, y;
-  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, w1_dev, K, D, 0, 0, &w1, D, s) ||
-      !pack_planes(sc, w2_dev, D, N, 0, 0, &w2, N, s))
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s, fl) || !pack_planes(sc, w1_dev, K, D, 0, 0, &w1, D, s, fl) ||
+      !pack_planes(sc, w2_dev, D, N, 0, 0, &w2, N, s, fl))
     return MSD_ERR_HIP;
   y.p[0] = sc.get<h16_t>((size_t)M * D); y.p[1] = sc.get<h16_t>((size_t)M * D);
   const int tiles = D / kNarrowTile;
@@ -1885,22 +1978,24 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     er.step_ptr = step; er.g_lo = g; er.g_lo_stride = 0; er.g_hi = g; er.g_hi_stride = 0; er.split_row = M / 2;
     GemmParams p1 = gp<2>(a, K, w1, K, M, D, K);
     p1.xcd_rows = 2; p1.xcd_walk_n = 1;
-    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 32, 32, 4>(p1, er, s);
+    fl.arm(p1);
+    if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, 32, 4>(p1, er, s);
     EpiStoreF32 ef;
     ef.out = h_out_dev; ef.ldc = N;
     ef.rsc.ssq = ssq; ef.rsc.tiles = tiles; ef.rsc.inv_d = 1.0f / (float)D; ef.rsc.bias = bw;
     ef.rsc.bias_step_stride = 0; ef.rsc.step_ptr = step;
-    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), ef, s);
+    if (e == hipSuccess) e = launch_gemm_h16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), ef, s);
   } else {
-    e = launch_gemm_bf16_dma<2, 32, 32, 4>(gp<2>(a, K, w1, K, M, D, K), EpiResidual{x_out_dev, D}, s);
+    e = launch_gemm_h16_dma<2, 32, 32, 4>(gp<2>(a, K, w1, K, M, D, K), EpiResidual{x_out_dev, D}, s);
     NormParams np;
     np.x = x_out_dev; np.gamma = gamma_dev; np.film = film_scale_dev ? film : nullptr; np.step_ptr = step;
     np.film_slots = 1; np.film_slot = 0; np.rows = M; np.D = D; np.out[0] = y.p[0]; np.out[1] = y.p[1]; np.out_f32 = nullptr;
+    fl.arm(np);
     hipLaunchKernelGGL((rmsnorm_film_kernel<1, 4>), dim3((M + 3) / 4), dim3(256), 0, s, np);
-    if (e == hipSuccess) e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), EpiStoreF32{h_out_dev, N}, s);
+    if (e == hipSuccess) e = launch_gemm_h16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), EpiStoreF32{h_out_dev, N}, s);
   }
   if (e != hipSuccess || hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
-  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+  return fl.finish(s);
 }
 
 // out[M, F] = gelu_tanh(a . wi0) * (a . wi1)   (layers.py:483-497): interleaved wi_0/wi_1 packing + EpiGeglu,
@@ -1910,18 +2005,22 @@ int msd_op_geglu(const float* a_dev, const float* wi0_dev, const float* wi1_dev,
   if (M % 64 || K % 64 || F % 64 || M <= 0 || !a_dev || !wi0_dev || !wi1_dev || !out_dev) return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   Scratch sc;
+  OpFlags fl;
+  if (!fl.init(sc)) return MSD_ERR_HIP;
   Planes a, wi, g;
-  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wi0_dev, K, F, 1, 0, &wi, 2 * F, s) ||
-      !pack_planes(sc, wi1_dev, K, F, 2, 0, &wi, 2 * F, s))
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s, fl) || !pack_planes(sc, wi0_dev, K, F, 1, 0, &wi, 2 * F, s, fl) ||
+      !pack_planes(sc, wi1_dev, K, F, 2, 0, &wi, 2 * F, s, fl))
     return MSD_ERR_HIP;
   g.p[0] = sc.get<h16_t>((size_t)M * F); g.p[1] = sc.get<h16_t>((size_t)M * F);
   if (!g.p[0] || !g.p[1]) return MSD_ERR_HIP;
   EpiGeglu<2> eg;
   eg.out[0] = g.p[0]; eg.out[1] = g.p[1]; eg.ldc = F;
-  hipError_t e = launch_gemm_bf16_dma<2, 64, 128, 3>(gp<2>(a, K, wi, K, M, 2 * F, K), eg, s);
+  GemmParams pg = gp<2>(a, K, wi, K, M, 2 * F, K);
+  fl.arm(pg);
+  hipError_t e = launch_gemm_h16_dma<2, 64, 128, 3>(pg, eg, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   merge(g, out_dev, (int64_t)M * F, s);
-  return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
+  return fl.finish(s);
 }
 
 // Fused q|k|v projection with the attention kernel's operand layouts (EpiQKV): q, k row-major, V^T per
@@ -1933,9 +2032,11 @@ int msd_op_qkv(const float* a_dev, const float* wq_dev, const float* wk_dev, con
     return MSD_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   Scratch sc;
+  OpFlags fl;
+  if (!fl.init(sc)) return MSD_ERR_HIP;
   Planes a, w, qk, vt;
-  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s) || !pack_planes(sc, wq_dev, K, J, 0, 0, &w, 3 * J, s) ||
-      !pack_planes(sc, wk_dev, K, J, 0, J, &w, 3 * J, s) || !pack_planes(sc, wv_dev, K, J, 0, 2 * J, &w, 3 * J, s))
+  if (!split_new(sc, a_dev, (int64_t)M * K, &a, s, fl) || !pack_planes(sc, wq_dev, K, J, 0, 0, &w, 3 * J, s, fl) ||
+      !pack_planes(sc, wk_dev, K, J, 0, J, &w, 3 * J, s, fl) || !pack_planes(sc, wv_dev, K, J, 0, 2 * J, &w, 3 * J, s, fl))
     return MSD_ERR_HIP;
   qk.p[0] = sc.get<h16_t>((size_t)M * 2 * J); qk.p[1] = sc.get<h16_t>((size_t)M * 2 * J);
   vt.p[0] = sc.get<h16_t>((size_t)M * J); vt.p[1] = sc.get<h16_t>((size_t)M * J);
@@ -1945,9 +2046,12 @@ int msd_op_qkv(const float* a_dev, const float* wq_dev, const float* wk_dev, con
   eq.qk[0] = qk.p[0]; eq.qk[1] = qk.p[1]; eq.vt[0] = vt.p[0]; eq.vt[1] = vt.p[1];
   eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = seg_len; eq.vt_ld = seg_len; eq.vt_rows = J;
   hipError_t e;
-  if ((3 * J) % 96 == 0 && (2 * J) % 96 == 0) e = launch_gemm_bf16_dma<2, 64, 96, 3>(gp<2>(a, K, w, K, M, 3 * J, K), eq, s);
-  else e = launch_gemm_bf16_dma<2, 64, 64, 3>(gp<2>(a, K, w, K, M, 3 * J, K), eq, s);
+  GemmParams pq = gp<2>(a, K, w, K, M, 3 * J, K);
+  fl.arm(pq);
+  if ((3 * J) % 96 == 0 && (2 * J) % 96 == 0) e = launch_gemm_h16_dma<2, 64, 96, 3>(pq, eq, s);
+  else e = launch_gemm_h16_dma<2, 64, 64, 3>(pq, eq, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
+  if (const int rc = fl.finish(s)) return rc;
   std::vector<float> h((size_t)M * 2 * J), qh((size_t)M * J), kh((size_t)M * J), vh((size_t)M * J);
   merge(qk, f32, (int64_t)M * 2 * J, s);
   if (hipMemcpyAsync(h.data(), f32, h.size() * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1995,7 +2099,7 @@ int msd_op_final_proj(const float* x_dev, const float* gamma_dev, const float* w
   EpiResidualNorm<2> er;
   er.x = x; er.ldx = D; er.y[0] = nullptr; er.y[1] = nullptr; er.ssq = ssq; er.tiles = tiles; er.step_ptr = step;
   er.g_lo = nullptr; er.g_lo_stride = 0; er.g_hi = nullptr; er.g_hi_stride = 0; er.split_row = 0;
-  hipError_t e = launch_gemm_bf16_dma<2, 32, 32, 4>(gp<2>(za, 64, zw, 64, M, D, 64), er, s);
+  hipError_t e = launch_gemm_h16_dma<2, 32, 32, 4>(gp<2>(za, 64, zw, 64, M, D, 64), er, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(scale_rows_kernel, dim3((D * n + 255) / 256), dim3(256), 0, s, w_dev, gamma_dev, wg, D, n);
   FinalProjParams fp;

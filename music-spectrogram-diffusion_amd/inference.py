@@ -182,7 +182,8 @@ class InferenceModel(object):
   """Wrapper of the HIP synthesizer with the reference's InferenceModel API."""
 
   def __init__(self, checkpoint_path, gin_config: Union[str, config_lib.ModelSpec],
-               batch_size: int = 1, precision: str = 'f16x3', device: Optional[int] = None):
+               batch_size: int = 1, precision: str = 'f16x3', device: Optional[int] = None,
+               range_fallback: bool = False):
     """Args mirror inference.py:71-88.
 
     gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
@@ -192,6 +193,10 @@ class InferenceModel(object):
       'bf16x3' (hi + lo bfloat16 planes: float32's exponent range, 2x the error; the
       other library build), 'f16' / 'bf16' (one plane, fastest; do NOT meet the bar).
     device: HIP device index (default: torch's current device).
+    range_fallback: what to do when an activation leaves the range of the half planes (|x| > 65504; the
+      library detects it and fails the call with native.RangeError -- the reference is float32 and has no such
+      limit): False (default) lets the error out; True switches this model to 'bf16x3' (bfloat16 planes:
+      float32's exponent range, twice the rounding error), once and for good, and repeats the call.
     """
     import torch  # device memory + streams only
     if isinstance(gin_config, config_lib.ModelSpec):
@@ -204,6 +209,7 @@ class InferenceModel(object):
     self.checkpoint_path = checkpoint_path
     self.batch_size = batch_size
     self.precision = precision
+    self.range_fallback = bool(range_fallback)
 
     self.sequence_length = dict(spec.task_feature_lengths)
     self.inputs_length = self.sequence_length['inputs']
@@ -264,9 +270,12 @@ class InferenceModel(object):
     if self._native is None:
       torch = self._torch
       with torch.cuda.device(self.device):
-        params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
+        if self._params_np is not None:   # rebuilt after a range fallback: same weights
+          params = self._params_np
+        else:
+          params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
         cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision)
-        nm = native.NativeModel(cfg, planes=native.plane_format(self.precision))
+        nm = native.NativeModel(cfg)   # the library build (plane format) follows from cfg.precision
         self._stream = torch.cuda.Stream(device=self.device)
         nm.load_weights(params, stream=self._stream.cuda_stream)
         self._params_np = params
@@ -299,6 +308,22 @@ class InferenceModel(object):
       seed for EVERY segment), `segment` does not enter the key in this mode.
     Returns (decodes float32 [B,T,n] in mel units, scores float32 [B] zeros).
     """
+    try:
+      return self._predict_once(batch, seed, segment, init_z, noise, return_torch, rng)
+    except native.RangeError:
+      if not (self.range_fallback and self.precision in ('f16x3', 'f16')):
+        raise
+      import warnings
+      new = 'bf16x3' if self.precision == 'f16x3' else 'bf16'
+      warnings.warn("an activation left the half-plane range (|x| > 65504): switching this model from precision "
+                    "'%s' to '%s' (bfloat16 planes) and repeating the call" % (self.precision, new), RuntimeWarning)
+      self.precision = new
+      if self._native is not None:
+        self._native.close()
+      self._native = None
+      return self._predict_once(batch, seed, segment, init_z, noise, return_torch, rng)
+
+  def _predict_once(self, batch, seed, segment, init_z, noise, return_torch, rng):
     torch = self._torch
     nm = self._get_native()
     dev = self.device

@@ -22,9 +22,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libmsd_amd.so')
 LIB_PATHS = {'f16': LIB_PATH, 'bf16': os.path.join(_HERE, 'csrc', 'libmsd_amd_bf16.so')}
 
-MSD_PREC_F16 = 0      # one 16-bit plane per operand
-MSD_PREC_F16X3 = 1    # hi + lo planes, three MFMAs per product (the parity mode)
-MSD_PREC_BF16, MSD_PREC_BF16X3 = MSD_PREC_F16, MSD_PREC_F16X3
+MSD_PREC_F16 = 0      # one IEEE-half plane per operand
+MSD_PREC_F16X3 = 1    # hi + lo half planes, three MFMAs per product (the parity mode, the default)
+MSD_PREC_BF16 = 2     # one bfloat16 plane                       } libmsd_amd_bf16.so; msd_create of the other
+MSD_PREC_BF16X3 = 3   # hi + lo bfloat16 planes                  } build answers MSD_ERR_UNSUPPORTED
 MSD_SAMPLER_DDPM = 0
 MSD_SAMPLER_DDIM = 1
 MAX_KERNEL_CLASSES = 16
@@ -34,7 +35,8 @@ MAX_KERNEL_CLASSES = 16
 # three MFMAs per product: the parity mode and the default) and 'f16' (one plane) --, libmsd_amd_bf16.so in
 # bfloat16 -- 'bf16x3' / 'bf16': 16 / 8 significand bits but float32's exponent range, for weights or activations
 # beyond the half range (|w| >= 128, |x| >= 131008).
-PRECISIONS = {'f16': MSD_PREC_F16, 'f16x3': MSD_PREC_F16X3, 'bf16': MSD_PREC_F16, 'bf16x3': MSD_PREC_F16X3}
+PRECISIONS = {'f16': MSD_PREC_F16, 'f16x3': MSD_PREC_F16X3, 'bf16': MSD_PREC_BF16, 'bf16x3': MSD_PREC_BF16X3}
+_PLANES_OF = {MSD_PREC_F16: 'f16', MSD_PREC_F16X3: 'f16', MSD_PREC_BF16: 'bf16', MSD_PREC_BF16X3: 'bf16'}
 
 
 def plane_format(precision: str) -> str:
@@ -48,13 +50,18 @@ EXPORTED_SYMBOLS = (
     'msd_version', 'msd_device_count', 'msd_create', 'msd_destroy', 'msd_last_error',
     'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
     'msd_encode', 'msd_sample', 'msd_reset_graph', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
-    'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
+    'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_h16', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
     'msd_op_attention', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
     'msd_op_qkv', 'msd_op_final_proj')
 
 
 class NativeLibraryError(RuntimeError):
   pass
+
+
+class RangeError(ArithmeticError):
+  """MSD_ERR_RANGE: an activation left the range of the IEEE-half operand planes (|x| > 65504) during the call;
+  its result is invalid.  The bfloat16-plane precisions ('bf16x3') have float32's exponent range."""
 
 
 MSD_SCHEDULE_COSINE, MSD_SCHEDULE_LINEAR = 0, 1
@@ -89,6 +96,11 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   if planes in _libs:
     return _libs[planes]
   LIB_PATH = LIB_PATHS[planes]
+  # same-box A/B of two builds (tools/ab_bench.sh): MSD_AMD_LIB=<path> replaces the half-plane library.  An older
+  # build may lack the newest entry points; those stay unbound (calling one raises AttributeError).
+  override = os.environ.get('MSD_AMD_LIB') if planes == 'f16' else None
+  if override:
+    LIB_PATH = override
   if not os.path.exists(LIB_PATH):
     raise NativeLibraryError(
         'HIP library not built: %s is missing. Build it with '
@@ -98,9 +110,9 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
   except OSError as e:  # missing ROCm runtime etc.
     raise NativeLibraryError('cannot load %s: %s' % (LIB_PATH, e)) from e
-  for sym in EXPORTED_SYMBOLS:
-    if not hasattr(lib, sym):
-      raise NativeLibraryError('%s does not export %s' % (LIB_PATH, sym))
+  present = [sym for sym in EXPORTED_SYMBOLS if hasattr(lib, sym)]
+  if len(present) != len(EXPORTED_SYMBOLS) and not override:
+    raise NativeLibraryError('%s does not export %s' % (LIB_PATH, sorted(set(EXPORTED_SYMBOLS) - set(present))))
   c = ctypes
   vp, i32, i64, u64, u32 = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_uint32
   lib.msd_version.restype = c.c_char_p
@@ -123,6 +135,8 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   lib.msd_debug_read.argtypes = [vp, c.c_char_p, vp, i64, c.POINTER(i64)]
   lib.msd_profile_steps.argtypes = [vp, i32, i32, c.POINTER(c.POINTER(c.c_char_p)),
                                     c.POINTER(c.c_double), c.POINTER(i64), vp]
+  if 'msd_op_gemm_h16' in present:
+    lib.msd_op_gemm_h16.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_gemm_bf16.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
@@ -131,7 +145,7 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   lib.msd_op_geglu.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_qkv.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   lib.msd_op_final_proj.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
-  for name in EXPORTED_SYMBOLS:
+  for name in present:
     fn = getattr(lib, name)
     if name not in ('msd_version', 'msd_last_error', 'msd_destroy'):
       fn.restype = i32
@@ -140,7 +154,7 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
 
 
 _EXC = {1: ValueError, 2: KeyError, 3: ValueError, 4: RuntimeError, 5: RuntimeError,
-        6: NotImplementedError}
+        6: NotImplementedError, 7: RangeError}
 
 
 def _check(lib, handle, rc, what):
@@ -162,7 +176,13 @@ def _ptr(t) -> Optional[int]:
 class NativeModel:
   """Owns one ``msd_model*`` on the current HIP device."""
 
-  def __init__(self, cfg: MsdConfig, planes: str = 'f16'):
+  def __init__(self, cfg: MsdConfig, planes: Optional[str] = None):
+    """`planes` (which library build) follows from cfg.precision; passing the other build's name is an error the
+    library itself reports (msd_create -> MSD_ERR_UNSUPPORTED -> NotImplementedError)."""
+    if planes is None:
+      if cfg.precision not in _PLANES_OF:
+        raise ValueError('unknown msd_precision %r' % (cfg.precision,))
+      planes = _PLANES_OF[cfg.precision]
     self.lib = load(planes)
     self.planes = planes
     self.cfg = cfg
@@ -286,14 +306,17 @@ def fill_normal(out, seed: int, stream_id: int, subseq: int, stream: int = 0):
     raise RuntimeError('msd_fill_normal failed (%d)' % rc)
 
 
-def op_gemm_bf16(precision: str, a, w, c, stream: int = 0):
-  """C = A.W with 16-bit operand planes in the format `precision` names (the symbol keeps its ABI-1 name)."""
+def op_gemm_h16(precision: str, a, w, c, stream: int = 0):
+  """C = A.W with 16-bit operand planes in the format `precision` names."""
   lib = load(plane_format(precision))
   m, k = a.shape
   n = w.shape[1]
-  rc = lib.msd_op_gemm_bf16(PRECISIONS[precision], _ptr(a), _ptr(w), _ptr(c), m, n, k, stream)
+  rc = lib.msd_op_gemm_h16(PRECISIONS[precision], _ptr(a), _ptr(w), _ptr(c), m, n, k, stream)
   if rc:
-    raise _EXC.get(rc, RuntimeError)('msd_op_gemm_bf16 failed (%d)' % rc)
+    raise _EXC.get(rc, RuntimeError)('msd_op_gemm_h16 failed (%d)' % rc)
+
+
+op_gemm_bf16 = op_gemm_h16   # ABI <= 2 name
 
 
 def op_gemm_f32(a, w, c, stream: int = 0):

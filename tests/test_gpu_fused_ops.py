@@ -212,6 +212,12 @@ def test_geglu_vs_oracle(env, m, k, f):
   wi0b[0, :] = 30.0   # gelu(30) == 30 in float32
   native.op_geglu(_dev(torch, a1), _dev(torch, wi0b), _dev(torch, wi1b), out)
   np.testing.assert_allclose(out.cpu().numpy()[0], 30.0 * np.arange(1, f + 1) / 32.0, rtol=1e-5)
+  # the round-2 form of this probe had wi_1 up to 255: beyond the half planes' |w| < 128.  It came back clamped
+  # (30 * 255.875) with MSD_OK; now the op refuses it like msd_finalize_weights does
+  wi1c = np.zeros((k, f), np.float32)
+  wi1c[0, :] = np.arange(1, f + 1) / 4.0
+  with pytest.raises(NotImplementedError):
+    native.op_geglu(_dev(torch, a1), _dev(torch, wi0b), _dev(torch, wi1c), out)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -20,25 +20,25 @@ def _dev(torch, a):
 
 @pytest.mark.parametrize('prec,tol', [('f16', 3e-3), ('f16x3', 1e-5), ('bf16', 2e-2), ('bf16x3', 2e-5)])
 @pytest.mark.parametrize('m,n,k', [(64, 64, 64), (256, 768, 768), (512, 128, 2048), (192, 320, 128)])
-def test_gemm_bf16(env, prec, tol, m, n, k):
+def test_gemm_h16(env, prec, tol, m, n, k):
   torch, native = env
   rng = np.random.default_rng(m + n + k)
   a = rng.standard_normal((m, k)).astype(np.float32)   # asymmetric, transpose-detecting
   w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
   c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
-  native.op_gemm_bf16(prec, _dev(torch, a), _dev(torch, w), c)
+  native.op_gemm_h16(prec, _dev(torch, a), _dev(torch, w), c)
   ref = a.astype(np.float64) @ w.astype(np.float64)
   err = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
   assert err < tol, err
 
 
-def test_gemm_bf16_identity_detects_transposes(env):
+def test_gemm_h16_identity_detects_transposes(env):
   torch, native = env
   k = 128
   a = np.eye(k, dtype=np.float32)[:64] * 1.0
   w = (np.arange(k * 192).reshape(k, 192) % 61).astype(np.float32)  # 512 w is exactly representable in one half plane
   c = torch.zeros((64, 192), dtype=torch.float32, device='cuda')
-  native.op_gemm_bf16('f16', _dev(torch, a), _dev(torch, w), c)
+  native.op_gemm_h16('f16', _dev(torch, a), _dev(torch, w), c)
   np.testing.assert_array_equal(c.cpu().numpy(), w[:64])
 
 
@@ -54,11 +54,51 @@ def test_gemm_operand_magnitudes(env, wscale, ascale, tol):
   a = (rng.standard_normal((m, k)) * ascale).astype(np.float32)
   w = (rng.standard_normal((k, n)) / np.sqrt(k) * wscale).astype(np.float32)
   c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
-  native.op_gemm_bf16('f16x3', _dev(torch, a), _dev(torch, w), c)
+  native.op_gemm_h16('f16x3', _dev(torch, a), _dev(torch, w), c)
   ref = a.astype(np.float64) @ w.astype(np.float64)
   err = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
   print('gemm f16x3, weights x%g, activations x%g: max rel err %.2e' % (wscale, ascale, err))
   assert err < tol, err
+
+
+def test_out_of_range_operands_fail_loudly_on_half_planes(env):
+  """Half planes hold |x| <= 65504 and |w| < 128.  Round 2 clamped both silently in the stand-alone ops (ADVICE r02:
+  a saturated GEGLU came back as 30 * 255.875 with MSD_OK); now an activation beyond the range is MSD_ERR_RANGE
+  (RangeError), a weight beyond it MSD_ERR_UNSUPPORTED (NotImplementedError, as msd_finalize_weights answers), and
+  the bfloat16-plane build takes both in its stride."""
+  torch, native = env
+  rng = np.random.default_rng(3)
+  m, n, k = 128, 128, 256
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  c = torch.zeros((m, n), dtype=torch.float32, device='cuda')
+  a_big = a.copy()
+  a_big[5, 7] = 2e5
+  with pytest.raises(native.RangeError):
+    native.op_gemm_h16('f16x3', _dev(torch, a_big), _dev(torch, w), c)
+  with pytest.raises(native.RangeError):
+    native.op_gemm_h16('f16', _dev(torch, a_big), _dev(torch, w), c)
+  a_edge = a.copy()
+  a_edge[5, 7] = 65504.0                      # the largest half: still in range
+  native.op_gemm_h16('f16x3', _dev(torch, a_edge), _dev(torch, w), c)
+  ref = a_edge.astype(np.float64) @ w.astype(np.float64)
+  assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-5
+  w_big = w.copy()
+  w_big[3, 3] = 200.0
+  with pytest.raises(NotImplementedError):
+    native.op_gemm_h16('f16x3', _dev(torch, a), _dev(torch, w_big), c)
+  for x, y in ((a_big, w), (a, w_big)):       # bfloat16 planes: float32's exponent range
+    native.op_gemm_h16('bf16x3', _dev(torch, x), _dev(torch, y), c)
+    ref = x.astype(np.float64) @ y.astype(np.float64)
+    assert np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
+  # attention: a query beyond the range
+  q = rng.standard_normal((64, 64)).astype(np.float32)
+  kk = rng.standard_normal((64, 64)).astype(np.float32)
+  o = torch.zeros((64, 64), dtype=torch.float32, device='cuda')
+  q[0, 0] = 1e5
+  with pytest.raises(native.RangeError):
+    native.op_attention('f16x3', _dev(torch, q), _dev(torch, kk), _dev(torch, kk), o, 1)
+  assert native.op_gemm_bf16 is native.op_gemm_h16      # ABI <= 2 name
 
 
 @pytest.mark.parametrize('m,n,k', [(64, 64, 16), (1000, 128, 768), (256, 768, 128), (7, 64, 32)])

@@ -68,7 +68,7 @@ def test_unsupported_and_unknown_configs_raise_like_the_reference():
   summed = dataclasses.replace(base, t5=dataclasses.replace(base.t5, decoder_cross_attend_style='sum_cross_attends'))
   assert inference._to_native_config(summed, codec, 1, 'bf16x3').cross_attend_sum == 1
   cfg = inference._to_native_config(base, codec, 2, 'bf16')
-  assert (cfg.emb_dim, cfg.context_length, cfg.max_batch, cfg.precision) == (128, 64, 2, 0)
+  assert (cfg.emb_dim, cfg.context_length, cfg.max_batch, cfg.precision) == (128, 64, 2, 2)   # MSD_PREC_BF16: its own value since ABI 3
 
 
 @pytest.mark.parametrize('always_mask', [False, True])

@@ -1,4 +1,4 @@
-"""The weight prefetch (csrc/gemm_bf16.h prefetch_weights) issues loads from inline asm into registers that the
+"""The weight prefetch (csrc/gemm_h16.h prefetch_weights) issues loads from inline asm into registers that the
 compiler must neither copy nor reuse before the kernel ends -- it does not know they are loads.  That cannot be
 expressed in the source; it is verified on the compiled device listing of the library (CPU only: hipcc cross-compiles)."""
 import os

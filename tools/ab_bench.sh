@@ -7,7 +7,7 @@ cp $LIB /tmp/lib_keep.so
 for r in $(seq $R); do
   for L in $A $B; do
     cp $L $LIB
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', d['value'], d['ms_per_step'])"
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', d['value'], d['ms_per_step'])"
   done
 done
 cp /tmp/lib_keep.so $LIB

@@ -1,4 +1,4 @@
-"""Static check of the weight-prefetch trick (csrc/gemm_bf16.h prefetch_weights): the inline-asm loads target
+"""Static check of the weight-prefetch trick (csrc/gemm_h16.h prefetch_weights): the inline-asm loads target
 registers the compiler must neither copy nor reuse before the kernel ends.  Scans a device assembly listing
 (hipcc --cuda-device-only -S) and fails if a destination register of such a load is mentioned again later in
 the same kernel as a DESTINATION (a read of a register pair that merely contains it, e.g. a packed-math broadcast

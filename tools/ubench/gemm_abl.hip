@@ -2,7 +2,7 @@
 //   0 full | 1 no MFMA | 2 no LDS fragment reads | 3 no DMA inside the loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 using namespace msd;
 template <int NP, int BM, int BN, int NS>
 double run(int M, int N, int K, int iters) {
@@ -10,11 +10,11 @@ double run(int M, int N, int K, int iters) {
   for (int i = 0; i < 2; ++i) { hipMalloc(&a[i], (size_t)M * K * 2); hipMalloc(&b[i], (size_t)N * K * 2); hipMalloc(&o[i], (size_t)M * N * 2);
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)N * K * 2); }
   GemmParams p; for (int i = 0; i < 2; ++i) { p.A[i] = a[i]; p.B[i] = b[i]; } p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0);
+  for (int i = 0; i < 5; ++i) launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0);
   hipDeviceSynchronize();
-  hipEventRecord(e0); for (int i = 0; i < iters; ++i) launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0); hipEventRecord(e1); hipEventSynchronize(e1);
+  hipEventRecord(e0); for (int i = 0; i < iters; ++i) launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   for (int i = 0; i < 2; ++i) { hipFree(a[i]); hipFree(b[i]); hipFree(o[i]); }
   return ms * 1e3 / iters;

@@ -1,11 +1,11 @@
-// Standalone timing + ablation harness for csrc/gemm_bf16.h on the DDPM step's GEMM shapes.
+// Standalone timing + ablation harness for csrc/gemm_h16.h on the DDPM step's GEMM shapes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DMSD_ABL=n] -o gemm_bench gemm_bench.hip
 // MSD_ABL: 0 full kernel; 1 no global loads in the loop; 2 no MFMA; 3 no ds_read; 4 no ds_write
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "gemm_bf16_regstaged.h"
+#include "gemm_h16_regstaged.h"
 using namespace msd;
 
 template <int NP, int BM, int BN, int R, bool DMA = false>
@@ -15,12 +15,12 @@ double run(int M, int N, int K, int iters, bool resid) {
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)N * K * 2); }
   hipMalloc(&c, (size_t)M * N * 4); hipMemset(c, 0, (size_t)M * N * 4);
   GemmParams p; for (int i = 0; i < 2; ++i) { p.A[i] = a[i]; p.B[i] = b[i]; } p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiResidual er{c, N}; EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiResidual er{c, N}; EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
 
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto go = [&]() {
-    if constexpr (DMA) { if (resid) launch_gemm_bf16_dma<NP, BM, BN, R>(p, er, 0); else launch_gemm_bf16_dma<NP, BM, BN, R>(p, es, 0); }
-    else { if (resid) launch_gemm_bf16<NP, BM, BN, R>(p, er, 0); else launch_gemm_bf16<NP, BM, BN, R>(p, es, 0); }
+    if constexpr (DMA) { if (resid) launch_gemm_h16_dma<NP, BM, BN, R>(p, er, 0); else launch_gemm_h16_dma<NP, BM, BN, R>(p, es, 0); }
+    else { if (resid) launch_gemm_h16<NP, BM, BN, R>(p, er, 0); else launch_gemm_h16<NP, BM, BN, R>(p, es, 0); }
   };
   // a second, unrelated kernel between launches so that weights are not L2-hot is NOT done here:
   // this measures the back-to-back (L2/MALL-warm) cost; the step re-reads each weight once per 2 ms.
@@ -42,11 +42,11 @@ double run_cold(int M, int N, int K, int iters, bool resid) {
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)COPIES * N * K * 2); }
   hipMalloc(&c, (size_t)M * N * 4); hipMemset(c, 0, (size_t)M * N * 4);
   GemmParams p; for (int i = 0; i < 2; ++i) p.A[i] = a[i]; p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiResidual er{c, N}; EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiResidual er{c, N}; EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto go = [&](int it) {
     for (int i = 0; i < 2; ++i) p.B[i] = b[i] + (size_t)(it % COPIES) * N * K;
-    if (resid) launch_gemm_bf16_dma<NP, BM, BN, NS>(p, er, 0); else launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0);
+    if (resid) launch_gemm_h16_dma<NP, BM, BN, NS>(p, er, 0); else launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0);
   };
   for (int i = 0; i < 5; ++i) go(i);
   hipDeviceSynchronize();

@@ -1,9 +1,9 @@
-// Large-M (batched songs) tile study for csrc/gemm_bf16.h: M = 2 * B * 256 rows.
+// Large-M (batched songs) tile study for csrc/gemm_h16.h: M = 2 * B * 256 rows.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_bench_big_0 gemm_bench_big.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 using namespace msd;
 
 template <int NP, int BM, int BN, int NS>
@@ -13,9 +13,9 @@ double run(int M, int N, int K, int iters, bool resid) {
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)N * K * 2); }
   hipMalloc(&c, (size_t)M * N * 4); hipMemset(c, 0, (size_t)M * N * 4);
   GemmParams p; for (int i = 0; i < 2; ++i) { p.A[i] = a[i]; p.B[i] = b[i]; } p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiResidual er{c, N}; EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiResidual er{c, N}; EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto go = [&]() { if (resid) launch_gemm_bf16_dma<NP, BM, BN, NS>(p, er, 0); else launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0); };
+  auto go = [&]() { if (resid) launch_gemm_h16_dma<NP, BM, BN, NS>(p, er, 0); else launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0); };
   for (int i = 0; i < 3; ++i) go();
   hipDeviceSynchronize();
   hipEventRecord(e0); for (int i = 0; i < iters; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_epi_0 gemm_epi.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 using namespace msd;
 
 template <class T> T* dmalloc(size_t n, int fill = 0) { T* p; (void)hipMalloc(&p, n * sizeof(T)); (void)hipMemset(p, fill, n * sizeof(T)); return p; }
@@ -13,7 +13,7 @@ template <int BM, int BN, int NS, class Epi>
 double timeit(GemmParams p, Epi epi, h16_t* b0, h16_t* b1, size_t bstride, int copies, int iters) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto go = [&](int it) { p.B[0] = b0 + (size_t)(it % copies) * bstride; p.B[1] = b1 + (size_t)(it % copies) * bstride;
-                          (void)launch_gemm_bf16_dma<2, BM, BN, NS>(p, epi, 0); };
+                          (void)launch_gemm_h16_dma<2, BM, BN, NS>(p, epi, 0); };
   for (int i = 0; i < 5; ++i) go(i);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0); for (int i = 0; i < iters; ++i) go(i + 5); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
@@ -38,7 +38,7 @@ int main() {
     EpiQKV<2> e; e.qk[0] = qk[0]; e.qk[1] = qk[1]; e.vt[0] = vt[0]; e.vt[1] = vt[1]; e.ld_qk = 2 * J; e.v_start = 2 * J; e.seg_len = T; e.vt_ld = T; e.vt_rows = J; e.rsc = rs;
     p.N = 3 * J;
     printf("qkv     64x96  EpiQKV        : %.1f us\n", timeit<64, 96, 3>(p, e, wq[0], wq[1], (size_t)3 * J * D, COPIES, 96));
-    EpiStoreBf16<2> s; s.out[0] = gout[0]; s.out[1] = gout[1]; s.ldc = 3 * J;
+    EpiStoreH16<2> s; s.out[0] = gout[0]; s.out[1] = gout[1]; s.ldc = 3 * J;
     printf("qkv     64x96  plain store   : %.1f us\n", timeit<64, 96, 3>(p, s, wq[0], wq[1], (size_t)3 * J * D, COPIES, 96));
     s.rsc = rs;
     printf("qkv     64x96  store+rowscale: %.1f us\n", timeit<64, 96, 3>(p, s, wq[0], wq[1], (size_t)3 * J * D, COPIES, 96));
@@ -49,7 +49,7 @@ int main() {
     EpiGeglu<2> e; e.out[0] = gact[0]; e.out[1] = gact[1]; e.ldc = F; e.rsc = rs;
     p.N = 2 * F;
     printf("mlp_in  64x128 EpiGeglu      : %.1f us\n", timeit<64, 128, 3>(p, e, wi[0], wi[1], (size_t)2 * F * D, COPIES, 96));
-    EpiStoreBf16<2> s; s.out[0] = gout[0]; s.out[1] = gout[1]; s.ldc = 2 * F;   // (gout is large enough: M * 2F / 2 planes.. use half)
+    EpiStoreH16<2> s; s.out[0] = gout[0]; s.out[1] = gout[1]; s.ldc = 2 * F;   // (gout is large enough: M * 2F / 2 planes.. use half)
     p.N = F;
     printf("mlp_in/2 64x128 plain store  : %.1f us (N = F only)\n", timeit<64, 128, 3>(p, s, wi[0], wi[1], (size_t)2 * F * D, COPIES, 96));
   }

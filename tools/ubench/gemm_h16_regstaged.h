@@ -1,8 +1,8 @@
 // Register-staged predecessor of the product GEMM (global -> register ring -> ds_write -> LDS), kept ONLY for
 // the ablation micro-benchmarks (tools/ubench/gemm_bench.hip): the product path uses the LDS-DMA kernel of
-// music-spectrogram-diffusion_amd/csrc/gemm_bf16.h, which this header includes for the shared pieces.
+// music-spectrogram-diffusion_amd/csrc/gemm_h16.h, which this header includes for the shared pieces.
 #pragma once
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 
 namespace msd {
 
@@ -11,7 +11,7 @@ namespace msd {
 #endif
 
 template <int NP, int BM, int BN, int R, class Epi>
-__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
+__global__ void __launch_bounds__(256) gemm_h16_kernel(GemmParams p, Epi epi) {
   constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile (2 x 2 waves)
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -190,24 +190,24 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmParams p, Epi epi) {
 }
 
 template <int NP, int BM, int BN, int R, class Epi>
-constexpr int gemm_bf16_smem() { return 2 * NP * (BM + BN) * 128; }
+constexpr int gemm_h16_smem() { return 2 * NP * (BM + BN) * 128; }
 
 // one-time opt-in to > 64 KiB dynamic LDS; call for every instantiation OUTSIDE stream capture
 template <int NP, int BM, int BN, int R, class Epi>
-inline hipError_t gemm_bf16_prepare() {
-  constexpr int smem = gemm_bf16_smem<NP, BM, BN, R, Epi>();
+inline hipError_t gemm_h16_prepare() {
+  constexpr int smem = gemm_h16_smem<NP, BM, BN, R, Epi>();
   if (smem < 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<NP, BM, BN, R, Epi>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_kernel<NP, BM, BN, R, Epi>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
 template <int NP, int BM, int BN, int R, class Epi>
-inline hipError_t launch_gemm_bf16(const GemmParams& p, const Epi& epi, hipStream_t stream) {
+inline hipError_t launch_gemm_h16(const GemmParams& p, const Epi& epi, hipStream_t stream) {
   // (> 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, set once in
   //  msd_api.hip:set_func_attrs -- never during stream capture)
-  constexpr int smem = gemm_bf16_smem<NP, BM, BN, R, Epi>();
-  auto kern = gemm_bf16_kernel<NP, BM, BN, R, Epi>;
-  static const hipError_t attr = gemm_bf16_prepare<NP, BM, BN, R, Epi>();
+  constexpr int smem = gemm_h16_smem<NP, BM, BN, R, Epi>();
+  auto kern = gemm_h16_kernel<NP, BM, BN, R, Epi>;
+  static const hipError_t attr = gemm_h16_prepare<NP, BM, BN, R, Epi>();
   if (attr != hipSuccess) return attr;
   const int grid = (p.M / BM) * (p.N / BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p, epi);

@@ -1,8 +1,8 @@
-// Fixed cost vs per-K-tile cost of the product GEMM (csrc/gemm_bf16.h) at the DDPM step's M = 512.
+// Fixed cost vs per-K-tile cost of the product GEMM (csrc/gemm_h16.h) at the DDPM step's M = 512.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_ksweep_0 gemm_ksweep.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_bf16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 using namespace msd;
 
 template <int NP, int BM, int BN, int NS>
@@ -12,9 +12,9 @@ double run(int M, int N, int K, int iters, bool cold_a = false) {
   for (int i = 0; i < 2; ++i) { hipMalloc(&a[i], (size_t)COPIES * M * K * 2); hipMalloc(&b[i], (size_t)COPIES * N * K * 2); hipMalloc(&o[i], (size_t)M * N * 2);
     hipMemset(a[i], 0x3c, (size_t)COPIES * M * K * 2); hipMemset(b[i], 0x3b, (size_t)COPIES * N * K * 2); }
   GemmParams p; for (int i = 0; i < 2; ++i) p.A[i] = a[i]; p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto go = [&](int it) { for (int i = 0; i < 2; ++i) { p.B[i] = b[i] + (size_t)(it % COPIES) * N * K; if (cold_a) p.A[i] = a[i] + (size_t)(it % COPIES) * M * K; } launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0); };
+  auto go = [&](int it) { for (int i = 0; i < 2; ++i) { p.B[i] = b[i] + (size_t)(it % COPIES) * N * K; if (cold_a) p.A[i] = a[i] + (size_t)(it % COPIES) * M * K; } launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0); };
   for (int i = 0; i < 5; ++i) go(i);
   hipDeviceSynchronize();
   hipEventRecord(e0); for (int i = 0; i < iters; ++i) go(i + 5); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "gemm_bf16.h"
+#include "gemm_h16.h"
 using namespace msd;
 
 // every launch reads a different copy of the weights (COPIES * bytes > L2 + MALL), as in the step
@@ -24,11 +24,11 @@ double run_cold(int M, int N, int K, int iters) {
     hipMemset(a[i], 0x3c, (size_t)M * K * 2); hipMemset(b[i], 0x3b, (size_t)COPIES * wbytes);
   }
   GemmParams p; for (int i = 0; i < 2; ++i) p.A[i] = a[i]; p.lda = K; p.ldb = K; p.M = M; p.N = N; p.K = K;
-  EpiStoreBf16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
+  EpiStoreH16<NP> es; es.out[0] = o[0]; es.out[1] = o[1]; es.ldc = N;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto go = [&](int it) {
     for (int i = 0; i < 2; ++i) p.B[i] = b[i] + (size_t)(it % COPIES) * N * K;
-    launch_gemm_bf16_dma<NP, BM, BN, NS>(p, es, 0);
+    launch_gemm_h16_dma<NP, BM, BN, NS>(p, es, 0);
   };
   for (int i = 0; i < 5; ++i) go(i);
   hipDeviceSynchronize();
