@@ -248,7 +248,9 @@ int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_de
 
 /* x_out = x_in + a.w1 ; h_out = (RMSNorm(x_out; gamma) (.) (film_scale+1) + film_bias) . w2
  * (layers.py:632-666 + the Dense that follows).  folded=1: the decoder's folded-norm epilogues
- * (EpiResidualNorm producer, row-scale + tabulated bias.W consumer); folded=0: separate norm kernel.
+ * (EpiResidualNorm producer, row-scale + tabulated bias.W consumer); folded=2: the same with the producer as the
+ * 4-way split-K launch the decoder's MLP output projection runs on (m % 64, d % 128, k % 256 == 0 and
+ * (m/64)(d/128) 4 <= compute units; launched three times over the same arrival counters); folded=0: separate norm kernel.
  * film_scale_dev / film_bias_dev [D] may both be NULL (plain RMSNorm).
  *   x [m,d]  a [m,k]  w1 [k,d]  gamma [d]  w2 [d,n]  x_out [m,d]  h_out [m,n]; m,k,d,n % 64 == 0 */
 int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_dev,

@@ -54,6 +54,7 @@ struct AttnParams {
   WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_h16.h)
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
   unsigned sat_tag = 1;
+  int qp = 0;                // query-side single-plane switches (attention_kernel QP), NP = 2 only
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -83,8 +84,12 @@ constexpr int attention_smem() {
 // QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
 // QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
 // (decoder self-attention at B = 1: 12 heads x 4 x 2 passes = 96 blocks of 64 rows).
-template <int NP, int NS, int QB, int PF = kPfNone>
+// QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
+// O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
+// (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
+template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams p) {
+  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2);
   constexpr int kRows = 32 * QB;                 // query rows per block
   constexpr int JPW = 16 / (QB * kAttKG);        // K (and V^T) DMA instructions per wave, plane and stage
   constexpr float NEG = -1e30f;
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
                                                    (((2 * sx + hi) ^ (krow & 7)) << 4));
         s = MSD_MFMA_32X32X16(kf[0], qf[0][sx], s, 0, 0, 0);
         if (NP == 2) {
-          s = MSD_MFMA_32X32X16(kf[0], qf[NP - 1][sx], s, 0, 0, 0);
+          if (!Q1) s = MSD_MFMA_32X32X16(kf[0], qf[NP - 1][sx], s, 0, 0, 0);
           s = MSD_MFMA_32X32X16(kf[NP - 1], qf[0][sx], s, 0, 0, 0);
         }
       }
@@ -242,11 +247,11 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
         uint32_t wh[4], wl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {   // softmax weights are in [0, 1]: no range check
-          if (NP == 2) split2_h16(pv[8 * ks + 2 * j], pv[8 * ks + 2 * j + 1], wh[j], wl[j]);
+          if (NP == 2 && !P1) split2_h16(pv[8 * ks + 2 * j], pv[8 * ks + 2 * j + 1], wh[j], wl[j]);
           else wh[j] = cvt2_h16(pv[8 * ks + 2 * j], pv[8 * ks + 2 * j + 1]);
         }
         pf[0][ks] = as_frag(make_uint4(wh[0], wh[1], wh[2], wh[3]));
-        if (NP == 2) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
+        if (NP == 2 && !P1) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
       }
       // ---- O^T += V^T . P^T -----------------------------------------------------------
       if (MSD_ATT_ABL == 4) { asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1])); } else
@@ -264,8 +269,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
         o0 = MSD_MFMA_32X32X16(vf[0][0], pf[0][ks], o0, 0, 0, 0);
         o1 = MSD_MFMA_32X32X16(vf[0][1], pf[0][ks], o1, 0, 0, 0);
         if (NP == 2) {
-          o0 = MSD_MFMA_32X32X16(vf[0][0], pf[NP - 1][ks], o0, 0, 0, 0);
-          o1 = MSD_MFMA_32X32X16(vf[0][1], pf[NP - 1][ks], o1, 0, 0, 0);
+          if (!P1) {
+            o0 = MSD_MFMA_32X32X16(vf[0][0], pf[NP - 1][ks], o0, 0, 0, 0);
+            o1 = MSD_MFMA_32X32X16(vf[0][1], pf[NP - 1][ks], o1, 0, 0, 0);
+          }
           o0 = MSD_MFMA_32X32X16(vf[NP - 1][0], pf[0][ks], o0, 0, 0, 0);
           o1 = MSD_MFMA_32X32X16(vf[NP - 1][1], pf[0][ks], o1, 0, 0, 0);
         }
@@ -376,13 +383,13 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   rc.commit(p.sat, p.sat_tag);
 }
 
-template <int NP, int NS, int QB>
+template <int NP, int NS, int QB, int QP>
 inline hipError_t attention_prepare_one() {
   constexpr int smem = attention_smem<NP, NS, QB>();
   if (smem < 64 * 1024) return hipSuccess;
-  const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone>),
+  const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone, QP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? 1 : 0>),
+  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? 1 : 0, QP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return a != hipSuccess ? a : b;
 }
@@ -393,15 +400,17 @@ constexpr int attention_ns() { return (NP == 2) ? 2 : 3; }
 
 template <int NP, int NS = attention_ns<NP>()>
 inline hipError_t attention_prepare() {
-  const hipError_t a = attention_prepare_one<NP, NS, 1>(), b = attention_prepare_one<NP, NS, 2>();
-  return a != hipSuccess ? a : b;
+  hipError_t e = hipSuccess, r;
+#define MSD_ATT_PREP(QB_, QP_) if ((r = attention_prepare_one<NP, NS, QB_, QP_>()) != hipSuccess) e = r;
+  MSD_ATT_PREP(1, 0) MSD_ATT_PREP(2, 0)
+  if constexpr (NP == 2) { MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3) }
+#undef MSD_ATT_PREP
+  return e;
 }
 
-template <int NP>
-inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hipStream_t stream) {
+template <int NP, int QP>
+inline void launch_attention_qp(const AttnParams& p, int heads, int segs, hipStream_t stream) {
   constexpr int NS = attention_ns<NP>();
-  static const hipError_t attr = attention_prepare<NP, NS>();
-  if (attr != hipSuccess) return attr;
   // 64-row blocks share K/V between two query blocks; when that leaves most of the 256 CUs without
   // a block, 32-row blocks (twice as many) finish sooner
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
@@ -411,11 +420,28 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
   if (blocks64 < 128) {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW>), g1, dim3(kAttKG * 64), smem1, stream, p);
-    else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone>), g1, dim3(kAttKG * 64), smem1, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW, QP>), g1, dim3(kAttKG * 64), smem1, stream, p);
+    else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone, QP>), g1, dim3(kAttKG * 64), smem1, stream, p);
   } else {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, PFW>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
-    else hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfNone>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, PFW, QP>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
+    else hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfNone, QP>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
+  }
+}
+
+template <int NP>
+inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hipStream_t stream) {
+  constexpr int NS = attention_ns<NP>();
+  static const hipError_t attr = attention_prepare<NP, NS>();
+  if (attr != hipSuccess) return attr;
+  if constexpr (NP == 2) {
+    switch (p.qp & 3) {
+      case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
+      case 2: launch_attention_qp<NP, 2>(p, heads, segs, stream); break;
+      case 3: launch_attention_qp<NP, 3>(p, heads, segs, stream); break;
+      default: launch_attention_qp<NP, 0>(p, heads, segs, stream); break;
+    }
+  } else {
+    launch_attention_qp<NP, 0>(p, heads, segs, stream);
   }
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;

@@ -125,6 +125,12 @@ struct GemmParams {
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
   unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
+  // split-K launches (gemm_h16_splitk_kernel): exchange workspace [tile][dest split][src split][BM][BN/SK] fp32,
+  // one monotonic arrival counter and SK placement words per tile, an error word (bit 16+: placement, low: timeout)
+  float* sk_part = nullptr;
+  unsigned* sk_cnt = nullptr;
+  unsigned* sk_xcc = nullptr;
+  int* sk_err = nullptr;
 };
 
 // where an epilogue reports an activation that left the half-plane range
@@ -177,9 +183,15 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // (gemm_h16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
 // kernel may have produced (A planes, residual tile, row statistics): 0 in the stand-alone kernel, 16 (sc1:
 // bypass the CU's L1, served by the XCD's L2) inside the XCD-resident chain kernels (chain.h).
-template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem) {
+// SK > 1 (split-K, gemm_h16_splitk_kernel): this block is split `ks` of SK over the K axis of output tile `tile_id`;
+// it multiplies K-tiles [ks K/SK, (ks+1) K/SK) and, after the exchange described at the kernel, runs the epilogue
+// on columns [n0 + ks BN/SK, +BN/SK) of the tile.
+constexpr int kSplitSpinLimit = 2000000;
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem, int ks = 0,
+                                          int tile_id = 0) {
   constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int BNE = BN / SK;                    // columns of the tile this block's epilogue owns
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE_BYTES = NP * (A_BYTES + B_BYTES);
@@ -200,8 +212,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   const h16_t* gb[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
-    ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8;
-    gb[pl] = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8;
+    ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
+    gb[pl] = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
   }
   const size_t a_step = (size_t)8 * p.lda, b_step = (size_t)8 * p.ldb;
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -227,7 +239,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / kGemmBK;
+  const int nk = p.K / SK / kGemmBK;
   // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
 #pragma unroll
   for (int s = 0; s < NS; ++s)
@@ -238,7 +250,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
   // over-wait by these few instructions) and the final vmcnt(0) covers them.
   char* const aux = smem + NS * STAGE_BYTES;
-  epi.template prefetch<BM, BN, CP>(aux, m0, n0, wave, lane);
+  const int n0e = n0 + (SK > 1 ? ks * BNE : 0);   // first column of the epilogue's share
+  epi.template prefetch<BM, BNE, CP>(aux, m0, n0e, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
 
   // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF (prologue only; the
@@ -395,22 +408,110 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_D_READ
 #undef MSD_D_ISSUE
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
-  // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
-  PrefetchRegsT<PF> pf_keep;
-  prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
-
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
+  auto store_slab = [&]() {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
-          make_float4(acc[i][j][0] * kWScaleInv, acc[i][j][1] * kWScaleInv, acc[i][j][2] * kWScaleInv,
-                      acc[i][j][3] * kWScaleInv);   // weights are packed times kWScale (common.h)
-  epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
-  __syncthreads();
-  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<float4*>(slab + (size_t)(wm * WM + i * 16 + lm) * LDS_LD + wn * WN + j * 16 + ln) =
+            make_float4(acc[i][j][0] * kWScaleInv, acc[i][j][1] * kWScaleInv, acc[i][j][2] * kWScaleInv,
+                        acc[i][j][3] * kWScaleInv);   // weights are packed times kWScale (common.h)
+  };
+  PrefetchRegsT<PF> pf_keep;
+  if constexpr (SK == 1) {
+    // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
+    prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
+    store_slab();
+    epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
+    __syncthreads();
+    epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+  } else {
+    // ---- split-K exchange: a reduce-scatter among the SK blocks of this tile --------------------------------
+    // Every block holds a full BM x BN partial.  It keeps the BNE columns it owns, hands the other SK-1 column
+    // groups to their owners through the workspace, and after ONE arrival barrier among the SK blocks sums the
+    // SK partials of its own columns (always in split order 0..SK-1: bit-reproducible) and runs the epilogue on
+    // them.  The SK blocks of a tile are laid out on ONE XCD (kernel wrapper), so plain stores land in the L2 the
+    // readers are served from and the L1-bypassing (sc1) LDS-DMA reads them back without any cache maintenance
+    // -- the pattern tools/ubench/xcd_sync.hip validated (500 rounds x 256 blocks, 0 stale words).  The block ->
+    // XCD placement is an OBSERVATION, not a contract: every block publishes its XCC_ID, every block compares its
+    // group's, and a mismatch (or a barrier timeout) raises p.sk_err, which fails the msd_* call that ran it.
+    constexpr int LDE = BNE + kSlabPad;
+    constexpr int Q4 = BM * BNE / 4;                       // float4 items of one column group
+    constexpr int SLAB_BYTES = (BM * LDS_LD + BM) * 4;
+    constexpr int STAGE_OFF = (SLAB_BYTES + 1023) / 1024 * 1024;         // SK-1 staged partials [BM][BNE], 1 KiB aligned
+    constexpr int SLABE_OFF = STAGE_OFF + (SK - 1) * BM * BNE * 4;       // the reduced tile [BM][LDE] (+ BM floats)
+    static_assert(SLABE_OFF + (BM * LDE + BM) * 4 <= NS * STAGE_BYTES, "split-K staging must fit the operand LDS");
+    static_assert((BM * BNE * 4) % 1024 == 0 && ((SK - 1) * BM * BNE * 4 / 1024) % 4 == 0, "whole DMA instructions per wave");
+    store_slab();
+    __syncthreads();
+    float* const part = p.sk_part + (size_t)tile_id * SK * SK * BM * BNE;
+    for (int it = tid; it < (SK - 1) * Q4; it += 256) {
+      const int qq = it / Q4, r = it % Q4;
+      const int q = qq + (qq >= ks ? 1 : 0);               // destination split (owner of these columns)
+      const int m = r / (BNE / 4), c4 = r % (BNE / 4);
+      const float4 v = *reinterpret_cast<const float4*>(slab + m * LDS_LD + q * BNE + c4 * 4);
+      *reinterpret_cast<float4*>(part + ((size_t)(q * SK + ks) * BM + m) * BNE + c4 * 4) = v;
+    }
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    if (tid == 0) __hip_atomic_store(p.sk_xcc + tile_id * SK + ks, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my stores have reached L2
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = p.sk_cnt + tile_id;
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (old / SK + 1) * SK;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (++spins > kSplitSpinLimit) { atomicAdd(p.sk_err, 1); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      bool same = true;
+#pragma unroll
+      for (int q = 0; q < SK; ++q)
+        same = same && __hip_atomic_load(p.sk_xcc + tile_id * SK + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc + 1u;
+      if (!same) atomicAdd(p.sk_err, 1 << 16);
+    }
+    __syncthreads();
+    {  // the SK-1 partials of MY columns: L1-bypassing LDS-DMA, 1 KiB per instruction, dealt over the 4 waves
+      typedef const __attribute__((address_space(1))) void* gp_t;
+      typedef __attribute__((address_space(3))) void* lp_t;
+      constexpr int N_INSTR = (SK - 1) * BM * BNE * 4 / 1024, PER_Q = BM * BNE * 4 / 1024;
+      for (int i = wave; i < N_INSTR; i += 4) {
+        const int qq = i / PER_Q, r = i % PER_Q;
+        const int q = qq + (qq >= ks ? 1 : 0);             // source split
+        const char* src = reinterpret_cast<const char*>(part + (size_t)(ks * SK + q) * BM * BNE) + r * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(smem + STAGE_OFF + i * 1024), 16, 0, 16 /* sc1 */);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the later launch's weights: touched AFTER the partials were requested (vmcnt retires in order), so that the
+    // counted wait below covers the partials and leaves these PF * kPrefetchPerThread touches in flight
+    prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * kPrefetchPerThread) : "memory");
+    __syncthreads();
+    float* const slabE = reinterpret_cast<float*>(smem + SLABE_OFF);
+    const float* const stage = reinterpret_cast<const float*>(smem + STAGE_OFF);
+    for (int it = tid; it < Q4; it += 256) {
+      const int m = it / (BNE / 4), c4 = it % (BNE / 4);
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < SK; ++q) {                       // split order, whoever owns the columns
+        float4 v;
+        if (q == ks) v = *reinterpret_cast<const float4*>(slab + m * LDS_LD + ks * BNE + c4 * 4);
+        else v = *reinterpret_cast<const float4*>(stage + ((size_t)(q - (q > ks ? 1 : 0)) * BM + m) * BNE + c4 * 4);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      *reinterpret_cast<float4*>(slabE + m * LDE + c4 * 4) = sum;
+    }
+    epi.template stats<BM, LDE>(slabE, m0, tid, aux);
+    __syncthreads();
+    epi.template run<BM, BNE, LDE>(slabE, m0, n0e, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+  }
   prefetch_done(pf_keep);
 }
 
@@ -435,6 +536,25 @@ __global__ void __launch_bounds__(256) gemm_h16_dma_kernel(GemmParams p, Epi epi
   }
   if (bn >= nbn || bm >= nbm) return;
   gemm_tile<NP, BM, BN, NS, Epi, 0, PF>(p, epi, bm, bn, smem);
+}
+
+// Split-K variant for the one GEMM of the step whose K is long and whose N is short (the MLP output projection,
+// M x D x F: 64 x 32 tiles over 32 K-tiles spent 9 of their 15.5 us streaming (64 + 32) rows per K-tile; SK blocks of
+// a 64 x 128 tile stream (64 + 128) rows over K / SK).  Grid = 8 XCDs x (tiles per XCD x SK) blocks, all resident
+// at once (host checks tiles * SK <= CUs: the blocks of a tile wait for each other).  Block b runs on XCD b % 8
+// (observed placement; verified in the kernel): XCD (xr, xc) of the xcd_rows x (8 / xcd_rows) grid owns the row
+// tiles [xr nbm / RX, +nbm / RX) x column tiles [xc nbn / CX, +nbn / CX); slot = b / 8 = (tile of that XCD, split).
+template <int NP, int BM, int BN, int NS, int SK, class Epi, int PF = kPfNone>
+__global__ void __launch_bounds__(256) gemm_h16_splitk_kernel(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nbm = p.M / BM, nbn = p.N / BN;
+  const int RX = p.xcd_rows, CX = 8 / RX;
+  const int nbm_x = nbm / RX, nbn_x = nbn / CX;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int g = slot / SK, ks = slot % SK;
+  if (g >= nbm_x * nbn_x) return;
+  const int bm = (xcd / CX) * nbm_x + g / nbn_x, bn = (xcd % CX) * nbn_x + g % nbn_x;
+  gemm_tile<NP, BM, BN, NS, Epi, 0, PF, SK>(p, epi, bm, bn, smem, ks, bm * nbn + bn);
 }
 
 // ----------------------------------------------------------------------------
@@ -983,6 +1103,45 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipSt
     MSD_LAUNCH_PF(0);
   }
 #undef MSD_LAUNCH_PF
+  return hipGetLastError();
+}
+
+// ---- split-K launch -------------------------------------------------------------------------------------------
+template <int NP, int BM, int BN, int NS, int SK, class Epi>
+constexpr int gemm_h16_splitk_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN / SK>(); }
+
+// (rows, columns) of the XCD grid for a split-K launch: as many column groups as divide the column tiles
+inline int splitk_xcd_rows(int nbm, int nbn) {
+  for (int cx = 4; cx >= 1; cx >>= 1)
+    if (nbn % cx == 0 && nbm % (8 / cx) == 0) return 8 / cx;
+  return 0;   // no grid fits: the caller keeps the plain kernel
+}
+
+// floats / words of workspace a split-K GEMM of M x N needs
+template <int BM, int BN, int SK>
+inline size_t splitk_part_floats(int M, int N) { return (size_t)(M / BM) * (N / BN) * SK * BM * BN; }
+
+template <int NP, int BM, int BN, int NS, int SK, class Epi>
+inline hipError_t gemm_h16_splitk_prepare() {
+  constexpr int smem = gemm_h16_splitk_smem<NP, BM, BN, NS, SK, Epi>();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return e != hipSuccess ? e : r;
+}
+
+// p.xcd_rows must come from splitk_xcd_rows(); p.sk_* must be set; (M/BM) * (N/BN) * SK blocks must be co-resident
+template <int NP, int BM, int BN, int NS, int SK, class Epi>
+inline hipError_t launch_gemm_h16_splitk(const GemmParams& p, const Epi& epi, hipStream_t stream) {
+  constexpr int smem = gemm_h16_splitk_smem<NP, BM, BN, NS, SK, Epi>();
+  static const hipError_t attr = gemm_h16_splitk_prepare<NP, BM, BN, NS, SK, Epi>();
+  if (attr != hipSuccess) return attr;
+  const int grid = (p.M / BM) * (p.N / BN) * SK;   // = 8 XCDs x tiles per XCD x SK
+  if (prefetch_kind(p.pf) >= 1)
+    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>), dim3(grid), dim3(256), smem, stream, p, epi);
+  else
+    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 0>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
 }
 

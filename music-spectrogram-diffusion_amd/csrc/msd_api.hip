@@ -163,6 +163,16 @@ struct msd_model {
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
+  // query-side single-plane attention (attention.h QP; MSD_ATT_QP_SELF / MSD_ATT_QP_CROSS = 0..3, decoder only)
+  int att_qp_self = 0, att_qp_cross = 0;
+  // split-K MLP output projection (gemm_h16.h gemm_h16_splitk_kernel; MSD_SPLITK=0: off)
+  bool splitk = true;
+  int splitk_min_k = 2048;     // K from which the split pays (MSD_SPLITK_MINK)
+  float* sk_part = nullptr;    // exchange workspace
+  unsigned* sk_cnt = nullptr;  // [tiles] arrival counters (zeroed at the start of every msd_* call that launches steps)
+  unsigned* sk_xcc = nullptr;  // [tiles][SK] placement words
+  int* d_sk_err = nullptr;     // low 16 bits: barrier timeouts; from bit 16: groups whose blocks were NOT on one XCD
+  size_t sk_tiles = 0;
   unsigned* d_sat = nullptr;   // half-plane range flag: kernel class + 1 of a conversion that saw |x| > 65504 (common.h RangeCheck)
   unsigned* h_sat = nullptr;   // pinned host copy, read after the stream sync that ends msd_encode / msd_sample
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
@@ -231,6 +241,35 @@ int check_range(msd_model* m, hipStream_t s, const char* what) {
               "float32's exponent range at twice the rounding error)", what, (double)kPlaneMax, cls);
 }
 
+
+// In-kernel synchronisation words (split-K arrival counters, chain barriers): fresh for every msd_* call that
+// launches decoder steps, and read back behind the call's final stream sync -- a timed-out wait or a block group
+// that was not placed on one XCD fails THAT call (gemm_h16.h gemm_tile SK > 1, chain.h).
+int reset_sync_words(msd_model* m, hipStream_t s) {
+  if (m->sk_cnt) {
+    HIP_TRY(m, hipMemsetAsync(m->sk_cnt, 0, sizeof(unsigned) * m->sk_tiles, s));
+    HIP_TRY(m, hipMemsetAsync(m->sk_xcc, 0, sizeof(unsigned) * m->sk_tiles * 4, s));
+  }
+  HIP_TRY(m, hipMemsetAsync(m->d_sk_err, 0, sizeof(int), s));
+  if (m->chain_mlp) {   // the arrival index of chain.h's barrier would wrap after ~1e8 barriers
+    HIP_TRY(m, hipMemsetAsync(m->d_bar, 0, sizeof(unsigned) * 8 * kBarStride, s));
+    HIP_TRY(m, hipMemsetAsync(m->d_chain_err, 0, sizeof(int), s));
+  }
+  return MSD_OK;
+}
+int check_sync_words(msd_model* m, const char* what) {   // call after the stream has been synchronised
+  int bad[2] = {0, 0};
+  HIP_TRY(m, hipMemcpy(&bad[0], m->d_sk_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (m->chain_mlp) HIP_TRY(m, hipMemcpy(&bad[1], m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad[0])
+    return fail(m, MSD_ERR_HIP, "%s: the split-K MLP output projection reported %d barrier timeouts and %d block groups "
+                "spread over several XCDs; the result of this call is invalid (MSD_SPLITK=0 selects the plain kernel)",
+                what, bad[0] & 0xffff, bad[0] >> 16);
+  if (bad[1])
+    return fail(m, MSD_ERR_HIP, "%s: an XCD-resident chain kernel timed out at a barrier (%d times); the result of this "
+                "call is invalid (MSD_CHAIN=0)", what, bad[1]);
+  return MSD_OK;
+}
 
 void add_weight(msd_model* m, const std::string& name, int64_t a, int64_t b = -1) {
   Weight w;
@@ -451,6 +490,29 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 #undef MSD_GO
 }
 
+// The MLP output projection as a 4-way split-K launch on 64 x 128 tiles (gemm_h16.h): only where all blocks of the
+// launch are resident at once (they wait for each other) and K is long enough to pay for the exchange.
+constexpr int kSkBM = 64, kSkBN = 128, kSkNS = 3, kSkSplit = 4;
+inline bool splitk_fits(const msd_model* m, int NP, int M, int N, int K) {
+  if (!m->splitk || NP != 2 || !m->sk_part || M % kSkBM || N % kSkBN || K % (kSkSplit * kGemmBK) || K < m->splitk_min_k) return false;
+  const int tiles = (M / kSkBM) * (N / kSkBN);
+  return tiles * kSkSplit <= m->cus && (size_t)tiles <= m->sk_tiles && splitk_xcd_rows(M / kSkBM, N / kSkBN) > 0 &&
+         M < big_m_threshold();
+}
+template <int NP, class Epi>
+void gemm_splitk(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi,
+                 const WeightPrefetch* pf) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  p.xcd_rows = splitk_xcd_rows(M / kSkBM, N / kSkBN);
+  p.sk_part = c.m->sk_part; p.sk_cnt = c.m->sk_cnt; p.sk_xcc = c.m->sk_xcc; p.sk_err = c.m->d_sk_err;
+  hipError_t e = launch_gemm_h16_splitk<NP, kSkBM, kSkBN, kSkNS, kSkSplit, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
 // Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_h16.h PrefetchTarget)
 template <int NP>
 PrefetchTarget weights_target(const msd_model* m, const Planes& w, int N, int K) {
@@ -512,7 +574,7 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -525,6 +587,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   p.total_rows = q_rows_per_seg * segs;
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -772,7 +835,7 @@ void encoder_stack(Ctx& c, const EncoderW& w, int rows, int n_valid_slot) {
     gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->eh, D, lw.attn.wqkv, D, rows, 3 * J, D, eq, eq.v_start);
     const h16_t* kp[2] = {m->eqk.p[0] + J, m->eqk.p[NP - 1] + J};
     attention<NP>(c, KC_ATTN_SELF, m->eqk, 2 * J, kp, 2 * J, 0, m->Lenc_pad, m->evt, m->Lenc_pad, 0, m->eao, J,
-                  m->d_nkeys_enc + n_valid_slot, rows, m->H, 1);
+                  m->d_nkeys_enc + n_valid_slot, rows, m->H, 1, 1, 0, nullptr, /*qp=*/0);
     gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->eao, J, lw.attn.wo, J, rows, D, J, EpiResidual{m->ex, D});
     norm<NP>(c, m->ex, lw.ln_mlp, rows, D, nullptr, 0, 0, &m->eh, nullptr);
     EpiGeglu<NP> eg;
@@ -1084,6 +1147,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
       const WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+      if constexpr (NP == 2) {
+        if (splitk_fits(m, NP, M, D, F)) {
+          gemm_splitk<NP>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, &pf_qkv);
+          continue;
+        }
+      }
       gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
     }
   }
@@ -1175,6 +1244,7 @@ void set_func_attrs() {
   (void)prepare_gemms<2>();
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
+  (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
 }
 
 }  // namespace
@@ -1243,6 +1313,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
   if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
+  if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
+  if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
+  if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
+  if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
   {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
@@ -1307,6 +1381,15 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_absmax, 1));
   TRY(dalloc(m, &m->d_sat, 1));
+  TRY(dalloc(m, &m->d_sk_err, 1));
+  if (D % kSkBN == 0 && Mmax % kSkBM == 0) {
+    m->sk_tiles = (Mmax / kSkBM) * (size_t)(D / kSkBN);
+    if (m->sk_tiles * kSkSplit <= (size_t)(m->cus > 0 ? m->cus : 0)) {
+      TRY(dalloc(m, &m->sk_part, m->sk_tiles * kSkSplit * kSkBM * kSkBN));
+      TRY(dalloc(m, &m->sk_cnt, m->sk_tiles));
+      TRY(dalloc(m, &m->sk_xcc, m->sk_tiles * kSkSplit));
+    }
+  }
   HIP_TRY(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_sat), sizeof(unsigned), hipHostMallocDefault));
   *m->h_sat = 0;
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
@@ -1538,10 +1621,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
-  if (m->chain_mlp) {   // chain.h: fresh barrier counters for every call (the arrival index would wrap after ~1e8 barriers)
-    HIP_TRY(m, hipMemsetAsync(m->d_bar, 0, sizeof(unsigned) * 8 * kBarStride, s));
-    HIP_TRY(m, hipMemsetAsync(m->d_chain_err, 0, sizeof(int), s));
-  }
+  if (int rc = reset_sync_words(m, s)) return rc;
   HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
 
   // One graph = `graph_steps` consecutive DDPM steps (the scan index lives in device memory, so
@@ -1584,12 +1664,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   // half-plane range flag and the chain kernels' barrier flag are read, so that a bad run fails THIS call.
   const int rc = check_range(m, s, "msd_sample");
   if (rc) return rc;
-  if (m->chain_mlp) {
-    int bad = 0;
-    HIP_TRY(m, hipMemcpy(&bad, m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (bad) return fail(m, MSD_ERR_HIP, "an XCD-resident chain kernel timed out at a barrier (%d times): the result of this call is invalid; set MSD_CHAIN=0", bad);
-  }
-  return MSD_OK;
+  return check_sync_words(m, "msd_sample");
 }
 
 int msd_reset_graph(msd_model* m) {
@@ -1613,6 +1688,7 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   const int st[2] = {step_index, step_index};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, st, sizeof(st), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipMemcpyAsync(m->z, z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (int rc = reset_sync_words(m, s)) return rc;
   HIP_TRY(m, hipStreamSynchronize(s));
   split_z(m, n, s);
   Ctx c{m, s};
@@ -1620,7 +1696,8 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   else { in_proj<1>(c, batch, 1); decoder_layers<1>(c, batch, 1, include_conditioning != 0); }
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "decoder pass failed: %s", hipGetErrorString(c.err));
   HIP_TRY(m, hipMemcpyAsync(eps_out_dev, m->eps, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return check_range(m, s, "msd_decoder_pass");   // synchronises
+  if (int rc = check_range(m, s, "msd_decoder_pass")) return rc;   // synchronises
+  return check_sync_words(m, "msd_decoder_pass");
 }
 
 int msd_get_schedule(const msd_model* m, float* host_out) {
@@ -1695,6 +1772,7 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
+  if (int rc2 = reset_sync_words(m, s)) return rc2;
   HIP_TRY(m, hipStreamSynchronize(s));
   for (int k = 0; k < KC_COUNT; ++k) { m->prof.ms[k] = 0; m->prof.launches[k] = 0; }
   m->prof.on = true;
@@ -1705,6 +1783,7 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   m->prof.on = false;
   HIP_TRY(m, hipStreamSynchronize(s));
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "profile run failed: %s", hipGetErrorString(c.err));
+  if (int rc2 = check_sync_words(m, "msd_profile_steps")) return rc2;
   for (int k = 0; k < MSD_MAX_KERNEL_CLASSES; ++k) {
     ms_out[k] = k < KC_COUNT ? m->prof.ms[k] : 0.0;
     launches_out[k] = k < KC_COUNT ? m->prof.launches[k] : 0;
@@ -1968,6 +2047,7 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     (void)hipMemcpyAsync(film + D, film_bias_dev, D * sizeof(float), hipMemcpyDeviceToDevice, s);
   }
   hipError_t e = hipSuccess;
+  int* sk_err = nullptr;
   if (folded) {
     hipLaunchKernelGGL(build_g_kernel, dim3((D + 255) / 256), dim3(256), 0, s, film, gamma_dev, g, 1, 1, 0, D);
     GemmF32Params bp;   // bias . W2 : one row
@@ -1979,7 +2059,24 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     GemmParams p1 = gp<2>(a, K, w1, K, M, D, K);
     p1.xcd_rows = 2; p1.xcd_walk_n = 1;
     fl.arm(p1);
-    if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, 32, 4>(p1, er, s);
+    if (folded == 2) {   // the producer as the decoder's 4-way split-K launch (gemm_h16_splitk_kernel)
+      int cus = 0, dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const int tiles = (M / kSkBM) * (D / kSkBN);
+      p1.xcd_rows = (M % kSkBM || D % kSkBN) ? 0 : splitk_xcd_rows(M / kSkBM, D / kSkBN);
+      if (p1.xcd_rows == 0 || K % (kSkSplit * kGemmBK) || tiles * kSkSplit > cus) return MSD_ERR_INVALID_ARGUMENT;
+      p1.sk_part = sc.get<float>((size_t)tiles * kSkSplit * kSkBM * kSkBN);
+      p1.sk_cnt = sc.get<unsigned>(tiles);
+      p1.sk_xcc = sc.get<unsigned>((size_t)tiles * kSkSplit);
+      sk_err = sc.get<int>(1);
+      p1.sk_err = sk_err;
+      if (!p1.sk_part || !p1.sk_cnt || !p1.sk_xcc || !sk_err) return MSD_ERR_HIP;
+      for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {   // three launches over the same (monotonic) arrival counters
+        if (rep) (void)hipMemcpyAsync(x_out_dev, x_in_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s);
+        e = launch_gemm_h16_splitk<2, kSkBM, kSkBN, kSkNS, kSkSplit>(p1, er, s);
+      }
+    } else if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, 32, 4>(p1, er, s);
     EpiStoreF32 ef;
     ef.out = h_out_dev; ef.ldc = N;
     ef.rsc.ssq = ssq; ef.rsc.tiles = tiles; ef.rsc.inv_d = 1.0f / (float)D; ef.rsc.bias = bw;
@@ -1995,7 +2092,12 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     if (e == hipSuccess) e = launch_gemm_h16_dma<2, 64, 64, 3>(gp<2>(y, D, w2, D, M, N, D), EpiStoreF32{h_out_dev, N}, s);
   }
   if (e != hipSuccess || hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
-  return fl.finish(s);
+  if (const int rc = fl.finish(s)) return rc;
+  if (sk_err) {   // split-K: barrier timeouts / block groups spread over several XCDs
+    int bad = 0;
+    if (hipMemcpy(&bad, sk_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || bad) return MSD_ERR_HIP;
+  }
+  return MSD_OK;
 }
 
 // out[M, F] = gelu_tanh(a . wi0) * (a . wi1)   (layers.py:483-497): interleaved wi_0/wi_1 packing + EpiGeglu,

@@ -357,7 +357,7 @@ def op_residual_norm_gemm(folded: bool, x_in, a, w1, gamma, film_scale, film_bia
   lib = load()
   m, k = a.shape
   d, n = w2.shape
-  _op_check(lib.msd_op_residual_norm_gemm(int(bool(folded)), _ptr(x_in), _ptr(a), _ptr(w1), _ptr(gamma),
+  _op_check(lib.msd_op_residual_norm_gemm(int(folded), _ptr(x_in), _ptr(a), _ptr(w1), _ptr(gamma),
                                           _ptr(film_scale), _ptr(film_bias), _ptr(w2), _ptr(x_out), _ptr(h_out),
                                           m, k, d, n, stream), 'msd_op_residual_norm_gemm')
 

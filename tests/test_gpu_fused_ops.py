@@ -148,7 +148,8 @@ def test_schedule_table_linear_and_cosine_vs_oracle(env):
 # folded RMSNorm + FiLM
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('film', [True, False])
-@pytest.mark.parametrize('m,k,d,n', [(128, 128, 256, 192), (512, 768, 768, 2304), (256, 2048, 768, 768)])
+@pytest.mark.parametrize('m,k,d,n', [(128, 128, 256, 192), (512, 768, 768, 2304), (256, 2048, 768, 768), (512, 2048, 768, 2304),
+                                     (512, 1024, 512, 1536), (128, 256, 128, 64)])
 def test_folded_norm_film_vs_oracle_and_unfolded(env, film, m, k, d, n):
   torch, native = env
   from oracle import backend, ops
@@ -169,7 +170,10 @@ def test_folded_norm_film_vs_oracle_and_unfolded(env, film, m, k, d, n):
     h = h * (sc.astype(np.float64) + 1.0) + bi.astype(np.float64)
   h_ref = h @ w2.astype(np.float64)
   res = {}
-  for folded in (True, False):
+  # 2 = the folded path with the producer on the decoder's split-K launch (MLP output projection shapes)
+  splitk = m % 64 == 0 and d % 128 == 0 and k % 256 == 0 and (m // 64) * (d // 128) * 4 <= 256 and any(
+      (d // 128) % cx == 0 and (m // 64) % (8 // cx) == 0 for cx in (4, 2, 1))   # gemm_h16.h splitk_xcd_rows
+  for folded in (True, False) + ((2,) if splitk else ()):
     x_out = torch.empty((m, d), dtype=torch.float32, device='cuda')
     h_out = torch.empty((m, n), dtype=torch.float32, device='cuda')
     native.op_residual_norm_gemm(folded, _dev(torch, x_in), _dev(torch, a), _dev(torch, w1), _dev(torch, gamma),
@@ -181,6 +185,8 @@ def test_folded_norm_film_vs_oracle_and_unfolded(env, film, m, k, d, n):
     assert ex < 2e-5 and eh < 4e-5
   # the fp32 residual stream is the same arithmetic on both paths
   np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-5 * np.abs(x_ref).max())
+  if splitk:   # four fp32 partial sums instead of one: same class
+    np.testing.assert_allclose(res[2][0], res[True][0], rtol=0, atol=1e-5 * np.abs(x_ref).max())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -215,7 +221,7 @@ def test_geglu_vs_oracle(env, m, k, f):
   # the round-2 form of this probe had wi_1 up to 255: beyond the half planes' |w| < 128.  It came back clamped
   # (30 * 255.875) with MSD_OK; now the op refuses it like msd_finalize_weights does
   wi1c = np.zeros((k, f), np.float32)
-  wi1c[0, :] = np.arange(1, f + 1) / 4.0
+  wi1c[0, :] = 200.0
   with pytest.raises(NotImplementedError):
     native.op_geglu(_dev(torch, a1), _dev(torch, wi0b), _dev(torch, wi1c), out)
 
