@@ -54,7 +54,13 @@ struct AttnParams {
   WeightPrefetch pf;    // optional: warm a later GEMM's weights in this XCD's L2 (gemm_h16.h)
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
   unsigned sat_tag = 1;
-  int qp = 0;                // query-side single-plane switches (attention_kernel QP), NP = 2 only
+  int qp = 0;                // query-side single-plane switches (attention_kernel QP bits 0 / 1), NP = 2 only
+  // Un-normalised queries (QP bit 2): q holds (x (.) gamma) . Wq WITHOUT the 1/rms of the RMSNorm in front of the
+  // projection (the hoisted cross-attention query projection, msd_api.hip); the kernel scales the logits of query
+  // row r by rstd[r] = rsqrt(sum_t q_ssq[r][t] * q_inv_d + 1e-6) -- the same algebra as the folded norms of the GEMMs.
+  const float* q_ssq = nullptr;   // [rows][q_tiles] partial sums of squares of the residual stream
+  int q_tiles = 0;                // <= 32 (multiple of 4)
+  float q_inv_d = 0.f;
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -87,9 +93,10 @@ constexpr int attention_smem() {
 // QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
 // O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
 // (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
+// Bit 2: the queries are un-normalised, see AttnParams::q_ssq.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams p) {
-  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2);
+  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2), QS = (QP & 4) != 0;
   constexpr int kRows = 32 * QB;                 // query rows per block
   constexpr int JPW = 16 / (QB * kAttKG);        // K (and V^T) DMA instructions per wave, plane and stage
   constexpr float NEG = -1e30f;
@@ -150,6 +157,15 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
   // ---- Q fragments (B operand of S^T = K.Q^T), straight from global; issued BEFORE the
   // ring DMAs so that the counted vmcnt waits below see them as the oldest operations ----
   const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * kRows + qb * 32 + q_lane;
+  // QS: the partial sums of squares of this lane's query row -- 8 unconditional 16-byte loads (branch-free: a
+  // conditional load on the way into the loop makes hipcc drain the ring's DMAs), issued before everything else
+  f32x4 qss[QS ? 8 : 1];
+  if constexpr (QS) {
+    const int n4 = p.q_tiles >> 2;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(p.q_ssq + qrow * p.q_tiles);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qss[i] = sp[i < n4 ? i : 0];
+  }
   frag8 qf[NP][4];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
@@ -168,6 +184,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = NEG, l_run = 0.f;
+  float q_rstd = 1.0f;
+  if constexpr (QS) {
+    const int n4 = p.q_tiles >> 2;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += (i < n4) ? (qss[i][0] + qss[i][1]) + (qss[i][2] + qss[i][3]) : 0.f;
+    q_rstd = 1.0f / sqrtf(acc * p.q_inv_d + 1e-6f);
+  }
 
   int buf = 0;
   for (int st = 0; st < nst; ++st) {
@@ -215,6 +239,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64) attention_kernel(AttnParams 
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) MSD_A_ISSUE(st + NS - 1, nb)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= q_rstd;   // one query per lane column: the row scale is a lane scalar
+      }
       // lane owns keys kb0 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
       float bmax = NEG;
       if (kb0 + 32 > nkeys) {  // only the last, ragged key block needs the bound
@@ -403,7 +431,11 @@ inline hipError_t attention_prepare() {
   hipError_t e = hipSuccess, r;
 #define MSD_ATT_PREP(QB_, QP_) if ((r = attention_prepare_one<NP, NS, QB_, QP_>()) != hipSuccess) e = r;
   MSD_ATT_PREP(1, 0) MSD_ATT_PREP(2, 0)
-  if constexpr (NP == 2) { MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3) }
+  if constexpr (NP == 2) {
+    MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3)
+    MSD_ATT_PREP(1, 4) MSD_ATT_PREP(2, 4) MSD_ATT_PREP(1, 5) MSD_ATT_PREP(2, 5) MSD_ATT_PREP(1, 6) MSD_ATT_PREP(2, 6)
+    MSD_ATT_PREP(1, 7) MSD_ATT_PREP(2, 7)
+  }
 #undef MSD_ATT_PREP
   return e;
 }
@@ -434,10 +466,14 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
   if constexpr (NP == 2) {
-    switch (p.qp & 3) {
+    switch ((p.qp & 3) | (p.q_ssq ? 4 : 0)) {
       case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
       case 2: launch_attention_qp<NP, 2>(p, heads, segs, stream); break;
       case 3: launch_attention_qp<NP, 3>(p, heads, segs, stream); break;
+      case 4: launch_attention_qp<NP, 4>(p, heads, segs, stream); break;
+      case 5: launch_attention_qp<NP, 5>(p, heads, segs, stream); break;
+      case 6: launch_attention_qp<NP, 6>(p, heads, segs, stream); break;
+      case 7: launch_attention_qp<NP, 7>(p, heads, segs, stream); break;
       default: launch_attention_qp<NP, 0>(p, heads, segs, stream); break;
     }
   } else {

@@ -224,8 +224,10 @@ __global__ void scale_clip_kernel(const float* in, float* out, int n, float fmin
 // W^T bf16 planes [N_out_rows, K]; dst row r takes source column src_col[r]
 // (identity, QKV concatenation, or the 16-column wi_0/wi_1 interleave).
 // ---------------------------------------------------------------------------
+// `ldk` (0 = K) is the row length of the destination and `k0` the first column written: K-concatenated weights
+// (the hoisted cross-attention query projection stacks two matrices along K).
 __global__ void pack_wt_kernel(const float* w, int K, int N, h16_t* hi, h16_t* lo,
-                               int dst_row0, int col_map_mode, int F, unsigned* absmax) {
+                               int dst_row0, int col_map_mode, int ldk, unsigned* absmax, int k0 = 0) {
   // grid: (ceil(K/64), N) ; block 64: thread = k within chunk
   const int n = blockIdx.y;
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -243,8 +245,9 @@ __global__ void pack_wt_kernel(const float* w, int K, int N, h16_t* hi, h16_t* l
   const float v = w0 * kWScale;   // undone on the accumulators (gemm_tile)
   h16_t h, l;
   split_h16(v, h, l);
-  hi[(size_t)dst * K + k] = h;
-  if (lo) lo[(size_t)dst * K + k] = l;
+  const int ld = ldk > 0 ? ldk : K;
+  hi[(size_t)dst * ld + k0 + k] = h;
+  if (lo) lo[(size_t)dst * ld + k0 + k] = l;
 }
 
 // token embedding (one-hot contraction == row gather, layers.py:556-559) + position

@@ -70,6 +70,8 @@ struct DecLayerW {
   Planes wq_cross[2];   // [J, D]
   Planes wkv_cross[2];  // [2J, D] (k|v)
   Planes wo_cross[2];   // [D, J]
+  // hoisted query projection of module 0 (decoder_layers): W^T of [Wq ; Wo_self . diag(gamma_cross) . Wq], [J, D + J]
+  Planes wq2;
   MlpW mlp;
 };
 struct EncoderW {
@@ -163,10 +165,16 @@ struct msd_model {
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
+  // Hoisted cross-attention query projection (decoder_layers; MSD_HOIST_Q=0: off): needs the folded norms, the
+  // two-plane mode, one cross-attention module and D % 128 == 0
+  bool hoist_q = true;
+  Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
   // query-side single-plane attention (attention.h QP; MSD_ATT_QP_SELF / MSD_ATT_QP_CROSS = 0..3, decoder only)
   int att_qp_self = 0, att_qp_cross = 0;
-  // split-K MLP output projection (gemm_h16.h gemm_h16_splitk_kernel; MSD_SPLITK=0: off)
-  bool splitk = true;
+  // split-K MLP output projection (gemm_h16.h gemm_h16_splitk_kernel).  OFF by default: measured 2.5 % SLOWER per
+  // step than the 64 x 32 tiles on the MI355X (profiles/r03b_env_ab.log: 1168 vs 1140 ms per segment; the exchange
+  // costs more than the shorter K loop wins); MSD_SPLITK=1 turns it on (parity-tested, tests/test_gpu_fused_ops.py)
+  bool splitk = false;
   int splitk_min_k = 2048;     // K from which the split pays (MSD_SPLITK_MINK)
   float* sk_part = nullptr;    // exchange workspace
   unsigned* sk_cnt = nullptr;  // [tiles] arrival counters (zeroed at the start of every msd_* call that launches steps)
@@ -382,6 +390,27 @@ constexpr int kNarrowTile = 32;  // BN of every GEMM that feeds the folded-norm 
 constexpr int kTallNS = 4;       // ring depth of the 64 x 32 tiles (6 measured equal in situ: 1.200 vs 1.198 ms)
 enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3, TK_SQUARE = 4 };
 
+// XCD grid (gemm_h16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
+// (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
+// the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
+// better than 1 x 8 everywhere.
+void set_xcd_grid(GemmParams& p, int kc, int M, int BM) {
+  int rx = 2, walk_n = 1;
+  if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
+  if (const char* v = getenv("MSD_XCD_WALK_N")) walk_n = atoi(v);
+  // per-class override for A/B runs: MSD_XCD_<class name, upper case>="rows,walk", e.g. MSD_XCD_GEMM_QKV=1,0
+  char name[64] = "MSD_XCD_";
+  size_t n = 8;
+  for (const char* q = kClassNames[kc]; *q && n + 1 < sizeof(name); ++q) name[n++] = (char)toupper(*q);
+  name[n] = 0;
+  if (const char* v = getenv(name)) {
+    int a = 0, b = 0;
+    if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0) { rx = a; walk_n = b; }
+  }
+  p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
+  p.xcd_walk_n = walk_n;
+}
+
 template <int NP, int BM, int BN, int NS, class Epi>
 void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
             const Epi& epi, const WeightPrefetch* pf = nullptr) {
@@ -389,26 +418,7 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  // XCD grid (gemm_h16.h): 2 row groups x 4 column groups.  Same-box A/B over the whole step
-  // (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
-  // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
-  // better than 1 x 8 everywhere.
-  {
-    int rx = 2, walk_n = 1;
-    if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
-    if (const char* v = getenv("MSD_XCD_WALK_N")) walk_n = atoi(v);
-    // per-class override for A/B runs: MSD_XCD_<class name, upper case>="rows,walk", e.g. MSD_XCD_GEMM_QKV=1,0
-    char name[64] = "MSD_XCD_";
-    size_t n = 8;
-    for (const char* q = kClassNames[kc]; *q && n + 1 < sizeof(name); ++q) name[n++] = (char)toupper(*q);
-    name[n] = 0;
-    if (const char* v = getenv(name)) {
-      int a = 0, b = 0;
-      if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0) { rx = a; walk_n = b; }
-    }
-    p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
-    p.xcd_walk_n = walk_n;
-  }
+  set_xcd_grid(p, kc, M, BM);
   hipError_t e = launch_gemm_h16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
@@ -574,7 +584,8 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1,
+               const float* q_ssq = nullptr) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -587,6 +598,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   p.total_rows = q_rows_per_seg * segs;
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  if (q_ssq) { p.q_ssq = q_ssq; p.q_tiles = c.m->D / kNarrowTile; p.q_inv_d = 1.0f / (float)c.m->D; }
   p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
@@ -608,11 +620,11 @@ void gemm32(Ctx& c, int kc, const float* A, int lda, const float* B, int ldb, in
 
 // ---- weight packing ----------------------------------------------------------
 int pack(msd_model* m, hipStream_t s, const float* w, int K, int N, Planes& dst, int dst_row0,
-         int mode) {
+         int mode, int ldk = 0, int k0 = 0) {
   dim3 grid((K + 63) / 64, N), block(64);
   hipLaunchKernelGGL(pack_wt_kernel, grid, block, 0, s, w, K, N, dst.p[0],
-                     m->NP == 2 ? dst.p[1] : (h16_t*)nullptr, dst_row0, mode, 0,
-                     reinterpret_cast<unsigned*>(m->d_absmax));
+                     m->NP == 2 ? dst.p[1] : (h16_t*)nullptr, dst_row0, mode, ldk,
+                     reinterpret_cast<unsigned*>(m->d_absmax), k0);
   HIP_TRY(m, hipGetLastError());
   return MSD_OK;
 }
@@ -1065,7 +1077,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
-      const WeightPrefetch pf = cond0 ? prefetch_of<NP>(m, w.wq_cross[0], J, D) : prefetch_of<NP>(m, w.mlp.wi, 2 * F, D);
+      const WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D)
+                                : (m->hoist_q && w.wq2.p[0] ? prefetch_of<NP>(m, w.wq2, J, D + J) : prefetch_of<NP>(m, w.wq_cross[0], J, D));
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
     }
@@ -1077,13 +1090,42 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
+    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1): its input is
+    // LN(x1) = rstd(x1) (x1 (.) gamma) with x1 = x0 + ao . Wo, so
+    //   (x1 (.) gamma) . Wq = [x0 (.) gamma | ao] . [Wq ; Wo . diag(gamma) . Wq]
+    // depends on nothing the out-projection computes: both GEMMs run in ONE launch (gemm_h16_dual_kernel), the
+    // 1/rms moves onto the logits inside the attention kernel (AttnParams::q_ssq), and the launch boundary in
+    // front of the query projection (6.2 us of a 93 us layer in round 2) disappears.  x0 (.) gamma arrives as the
+    // planes `yc`, written by whichever epilogue produced x0 (input projection / previous layer's MLP output).
+    const bool hoist = m->hoist_q && cond0 && NP == 2 && row0 == 0 && pick_tile<NP, TK_SQUARE>(M, D, 0).bm == kNarrowTile &&
+                       pick_tile<NP, TK_SQUARE>(BT, J, 0).bm == kNarrowTile;
+    if (hoist) {
+      if constexpr (NP == 2) {
+        er.g_lo = nullptr; er.g_lo_stride = 0;   // the conditional rows' y = x1 (.) gamma_cross has no reader any more
+        GemmParams p1 = gp<NP>(ao, J, w.self.wo, J, M, D, J);
+        p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_ATTN_OUT + 1u;
+        set_xcd_grid(p1, KC_GEMM_ATTN_OUT, M, kNarrowTile);
+        p1.pf = prefetch_of<NP>(m, w.wo_cross[0], D, J);
+        GemmParams p2 = gp<NP>(m->yc, D, w.wq2, D + J, BT, J, D + J);
+        p2.A2[0] = ao.p[0]; p2.A2[1] = ao.p[NP - 1]; p2.lda2 = J; p2.k_split = D;
+        p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
+        set_xcd_grid(p2, KC_GEMM_CROSS_Q, BT, kNarrowTile);
+        EpiStoreH16<NP> es;
+        es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // rsc stays empty: stored un-normalised
+        c.begin(KC_GEMM_ATTN_OUT);
+        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4>(p1, er, p2, es, c.s);
+        if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+        c.end(KC_GEMM_ATTN_OUT);
+      }
+    } else {
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
+    }
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
       // projections run before the first output projection rewrites y
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
-      for (int e = 0; e < m->n_cross; ++e) {
+      for (int e = 0; e < m->n_cross && !hoist; ++e) {
         const Planes& cq = e == 0 ? m->cq : m->cq2;
         EpiStoreH16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
@@ -1104,7 +1146,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         const WeightPrefetch pf = (e + 1 == m->n_cross && !chain) ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
-                      batch, ks, region, &pf);
+                      batch, ks, region, &pf, -1, hoist ? ssq : nullptr);
       }
       // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
       // other; the last one also writes the folded-norm inputs of the MLP block
@@ -1126,6 +1168,9 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
+    if (m->hoist_q && cond0 && !last && row0 == 0) {   // x (.) gamma_cross of the NEXT layer, conditional rows
+      eo.y2[0] = m->yc.p[0]; eo.y2[1] = m->yc.p[NP - 1]; eo.g2 = m->dec[l + 1].ln_cross; eo.y2_rows = BT;
+    }
     if constexpr (NP == 2) {
       if (chain) {   // MLP-in -> MLP-out -> QKV of layer l+1: one XCD-resident launch (chain.h)
         MlpChainParams<NP> cp;
@@ -1189,6 +1234,7 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
+  if (m->hoist_q) { ei.y2[0] = m->yc.p[0]; ei.y2[1] = m->yc.p[NP - 1]; ei.g2 = m->dec[0].ln_cross; }
   const WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
@@ -1245,6 +1291,7 @@ void set_func_attrs() {
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
+  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiStoreH16<2>>();
 }
 
 }  // namespace
@@ -1313,6 +1360,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
   if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
+  if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
   if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
   if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
@@ -1339,6 +1387,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->key_off[0] = 0; m->key_off[1] = round_up(m->L, 64);
   if (m->n_cross == 2 && !m->fold_norm) return bad("sum_cross_attends needs the folded-norm path (MSD_FOLD_NORM=1)");
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
+  m->hoist_q = m->hoist_q && m->fold_norm && m->NP == 2 && m->n_cross == 1 && m->D % 128 == 0 && !m->dual_chain && !m->chain_mlp;
   declare_weights(m);
   *out = m;
   set_func_attrs();
@@ -1356,6 +1405,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
   TRY(palloc(m, &m->zp, (size_t)m->Bmax * T * m->ND));
+  if (m->hoist_q) TRY(palloc(m, &m->yc, (size_t)m->Bmax * T * D));
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
   m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
@@ -1504,6 +1554,29 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross[e], 0, 0))) return rc;
     }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
+    if (m->hoist_q) {
+      // q' = (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  [x0 (.) gamma | ao] . [Wq ; Wo . diag(gamma) . Wq]:
+      // the second block in float32 on the exact-fp32 MFMA, then both packed side by side along K
+      const std::string cp = lp + "/MultiHeadDotProductAttention_0";
+      float *gwq = nullptr, *w2 = nullptr;
+      HIP_TRY(m, hipMalloc(&gwq, (size_t)D * J * sizeof(float)));
+      HIP_TRY(m, hipMalloc(&w2, (size_t)J * J * sizeof(float)));
+      hipLaunchKernelGGL(scale_rows_kernel, dim3((D * J + 255) / 256), dim3(256), 0, s, W(m, cp + "/query/kernel"),
+                         w.ln_cross, gwq, D, J);
+      GemmF32Params gp2;
+      gp2.A = W(m, lp + "/self_attention/out/kernel"); gp2.B = gwq; gp2.lda = D; gp2.ldb = J; gp2.M = J; gp2.N = J; gp2.K = D;
+      hipError_t e = launch_gemm_f32(gp2, EpiF32Store{w2, J}, s);
+      if (e == hipSuccess) {
+        if ((rc = palloc(m, &w.wq2, (size_t)J * (D + J))) == MSD_OK &&
+            (rc = pack(m, s, W(m, cp + "/query/kernel"), D, J, w.wq2, 0, 0, D + J, 0)) == MSD_OK)
+          rc = pack(m, s, w2, J, J, w.wq2, 0, 0, D + J, D);
+      }
+      const hipError_t es = hipStreamSynchronize(s);
+      (void)hipFree(gwq); (void)hipFree(w2);
+      if (rc) return rc;
+      HIP_TRY(m, e);
+      HIP_TRY(m, es);
+    }
   }
   m->dec_final_ln = W(m, "decoder/decoder_norm/scale");
   m->w_spec_out = W(m, "decoder/spec_out_dense/kernel");

@@ -387,6 +387,50 @@ def test_xcd_resident_chain_kernel_matches_separate_launches(monkeypatch):
 
 
 @pytest.mark.parametrize('preset,mask', [('tiny_context', 'ragged'), ('tiny_context', 'zeros'), ('tiny', 'ones')])
+def test_hoisted_cross_query_projection_matches_the_plain_order(monkeypatch, preset, mask):
+  """MSD_HOIST_Q (default on): the cross-attention query projection runs in the launch of the self-attention
+  output projection, on [x0 (.) gamma | attention output] . [Wq ; Wo diag(gamma) Wq], and the RMSNorm's 1/rms is
+  applied to the logits inside the attention kernel (csrc/msd_api.hip decoder_layers).  Exact algebra, different
+  rounding order: single decoder passes must agree with the un-hoisted order far inside the float32 class, both
+  must sit on the float64 oracle, and a sampled segment stays in the float32 class."""
+  import torch
+  from oracle import backend, fast
+  spec = msd_amd.config.preset(preset, num_steps=6)
+  params = msd_amd.synthetic.init_params(spec, 11, norm_scale_jitter=0.3)
+  batch = helpers.make_batch(spec, batch=2, ctx_mask=mask) if spec.has_context else helpers.make_batch(spec, batch=2)
+  init_z, noise = helpers.make_noise(spec, batch=2)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend('float64')
+  fm = fast.FastModel(xp, cfg, dc, params, spec.has_context)
+  if spec.has_context:
+    fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+  else:
+    fm.encode(batch['encoder_input_tokens'])
+  outs, eps = {}, {}
+  for hoist in ('0', '1'):
+    monkeypatch.setenv('MSD_HOIST_Q', hoist)
+    model = msd_amd.InferenceModel(params, spec, batch_size=2)
+    outs[hoist], _ = model.predict(batch, init_z=init_z, noise=noise)
+    nm = model._get_native()
+    z = torch.as_tensor(init_z).cuda()
+    e = torch.zeros_like(z)
+    for step in (5, 0):
+      nm.decoder_pass(2, step, z, True, e)
+      torch.cuda.synchronize()
+      eps[hoist, step] = e.cpu().numpy().astype(np.float64)
+  for step in (5, 0):
+    ref = xp.to_numpy(fm.decoder_pass(xp.asarray(init_z), step, True)).astype(np.float64)
+    rel = np.abs(eps['1', step] - eps['0', step]).max() / np.abs(eps['0', step]).max()
+    e1 = np.abs(eps['1', step] - ref).max() / np.abs(ref).max()
+    e0 = np.abs(eps['0', step] - ref).max() / np.abs(ref).max()
+    print('%s/%s step %d: hoisted vs plain %.2e; vs float64 oracle: hoisted %.2e, plain %.2e' % (preset, mask, step, rel, e1, e0))
+    assert rel < 5e-5 and e1 < 2e-4 and e0 < 2e-4
+  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+  helpers.assert_fp32_class(outs['1'], ref64, ref32, 'hoisted query projection')
+
+
+@pytest.mark.parametrize('preset,mask', [('tiny_context', 'ragged'), ('tiny_context', 'zeros'), ('tiny', 'ones')])
 def test_sum_cross_attends_style(preset, mask):
   """decoder_cross_attend_style='sum_cross_attends' (the T5Config dataclass default, network.py:199-216): one
   cross-attention module per encoding (own q/k/v/out kernels, own key region and key count in the cache),
