@@ -115,6 +115,44 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
   for (int u = 0; u < (PF > 0 ? PF * kPrefetchPerThread : 1); ++u) asm volatile("" ::"v"(keep.r[u]));
 }
 
+// The same touches from a wave of their own: the block is launched with 64 extra threads, and that wave does
+// nothing but touch the later launch's operands and end (`pf_wave` in the launch parameters).  Its loads are on
+// ITS vmcnt counter: the compute waves never wait for them -- the in-epilogue form above makes every producer wait
+// at s_endpgm for touches it issued a microsecond earlier (cross-attention 11.6 -> 13.3 us) -- and the
+// touches leave at the start of the launch instead of behind its main loop, which gives the lines that much more
+// time to arrive before their consumer starts.  An ended wave no longer counts at s_barrier, so the compute
+// waves' barriers are unaffected once it has gone.  One wave issues what the four compute waves issued together.
+#ifndef MSD_PF_WAVE
+#define MSD_PF_WAVE 0   // build-time choice between the two prefetch mechanisms (A/B: tools/ab/r03_call4.sh)
+#endif
+constexpr bool kPfWave = MSD_PF_WAVE != 0;
+template <int PF>
+__device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk, int nblk, const void* valid) {
+  if constexpr (PF != kPfNone) {
+    constexpr int TOUCHES = 4 * kPrefetchPerThread;
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const PrefetchTarget& t = pf.t[k];
+      const int rows = t.rows, lpr = t.lpr;
+      const int planes = t.base[1] && t.base[1] != t.base[0] ? 2 : 1;
+      const int rpt = 64 >> t.lg;
+      const int sub = lane >> t.lg, line = lane & ((1 << t.lg) - 1);
+      const uint32_t lane_off = (uint32_t)sub * (uint32_t)t.row_stride + (uint32_t)line * 128u;
+#pragma unroll
+      for (int u = 0; u < TOUCHES; ++u) {
+        const int rp0 = (blk + nblk * u) * rpt;
+        const int pl = (planes == 2 && rp0 >= rows) ? 1 : 0, row0 = rp0 - pl * rows;
+        const char* row_ptr = t.base[pl] + (size_t)row0 * t.row_stride;
+        const bool in = rp0 < rows * planes && row0 + sub < rows && line < lpr;
+        const char* src = in ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
+        uint32_t sink;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
+      }
+    }
+  }
+}
+
 struct GemmParams {
   const h16_t* A[2];
   const h16_t* B[2];
@@ -437,7 +475,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   PrefetchRegsT<PF> pf_keep;
   if constexpr (SK == 1) {
     // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
-    prefetch_weights<PF>(p.pf, blockIdx.x, p.pf_nblk > 0 ? p.pf_nblk : (int)gridDim.x, p.B[0], pf_keep);
+    if constexpr (!kPfWave) prefetch_weights<PF>(p.pf, blockIdx.x, p.pf_nblk > 0 ? p.pf_nblk : (int)gridDim.x, p.B[0], pf_keep);
+    else prefetch_weights<kPfNone>(p.pf, 0, 1, nullptr, reinterpret_cast<PrefetchRegsT<kPfNone>&>(pf_keep));
     store_slab();
     epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
     __syncthreads();
@@ -484,12 +523,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
         if (++spins > kSplitSpinLimit) { atomicAdd(p.sk_err, 1); break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      // placement words of the group: independent L1-bypassing loads, all in flight together (one round trip)
+      // placement words of the group: SK independent L1-bypassing loads (all in flight together), then compared
       unsigned seen[SK];
 #pragma unroll
       for (int q = 0; q < SK; ++q)
-        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen[q]) : "v"(p.sk_xcc + tile_id * SK + q) : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        seen[q] = __hip_atomic_load(p.sk_xcc + tile_id * SK + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bool same = true;
 #pragma unroll
       for (int q = 0; q < SK; ++q) same = same && seen[q] == xcc + 1u;
@@ -510,9 +548,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     __builtin_amdgcn_sched_barrier(0);
     // the later launch's weights: touched AFTER the partials were requested (vmcnt retires in order), so that the
     // counted wait below covers the partials and leaves these PF * kPrefetchPerThread touches in flight
-    prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * kPrefetchPerThread) : "memory");
+    if constexpr (!kPfWave) {
+      prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * kPrefetchPerThread) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     float* const slabE = reinterpret_cast<float*>(smem + SLABE_OFF);
     const float* const stage = reinterpret_cast<const float*>(smem + STAGE_OFF);
@@ -535,9 +577,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   prefetch_done(pf_keep);
 }
 
+constexpr int pf_threads(int pf) { return kPfWave && pf != kPfNone ? 64 : 0; }   // the prefetch wave of a launch, if any
+
 template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
-__global__ void __launch_bounds__(256) gemm_h16_dma_kernel(GemmParams p, Epi epi) {
+__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (kPfWave && PF != kPfNone) {
+    if (threadIdx.x >= 256) {   // the prefetch wave (only launched with pf_wave)
+      prefetch_wave<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0]);
+      return;
+    }
+  }
   // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
   // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
   // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
@@ -565,8 +615,14 @@ __global__ void __launch_bounds__(256) gemm_h16_dma_kernel(GemmParams p, Epi epi
 // (observed placement; verified in the kernel): XCD (xr, xc) of the xcd_rows x (8 / xcd_rows) grid owns the row
 // tiles [xr nbm / RX, +nbm / RX) x column tiles [xc nbn / CX, +nbn / CX); slot = b / 8 = (tile of that XCD, split).
 template <int NP, int BM, int BN, int NS, int SK, class Epi, int PF = kPfNone>
-__global__ void __launch_bounds__(256) gemm_h16_splitk_kernel(GemmParams p, Epi epi) {
+__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_splitk_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (kPfWave && PF != kPfNone) {
+    if (threadIdx.x >= 256) {
+      prefetch_wave<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0]);
+      return;
+    }
+  }
   const int nbm = p.M / BM, nbn = p.N / BN;
   const int RX = p.xcd_rows, CX = 8 / RX;
   const int nbm_x = nbm / RX, nbn_x = nbn / CX;
@@ -583,8 +639,14 @@ __global__ void __launch_bounds__(256) gemm_h16_splitk_kernel(GemmParams p, Epi 
 // per layer, and the longer K loop starts first.  Each problem keeps its own XCD-aware tile map (n2 is a multiple
 // of 8, so a block's XCD is the same in the launch-wide and in the problem-local numbering).
 template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone>
-__global__ void __launch_bounds__(256) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n2) {
+__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (kPfWave && PF != kPfNone) {
+    if (threadIdx.x >= 256) {   // prefetch wave: every block of the launch takes part
+      prefetch_wave<PF>(p2.pf, blockIdx.x, gridDim.x, p1.B[0]);
+      return;
+    }
+  }
   const bool second = (int)blockIdx.x < n2;
   const GemmParams& p = second ? p2 : p1;
   const int b = second ? (int)blockIdx.x : (int)blockIdx.x - n2;
@@ -1179,7 +1241,7 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipSt
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
   // one kernel instantiation per number of prefetch targets (single path: see prefetch_weights)
 #define MSD_LAUNCH_PF(PF_) \
-  hipLaunchKernelGGL((gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256), smem, stream, p, epi)
+  hipLaunchKernelGGL((gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256 + pf_threads(PF_)), smem, stream, p, epi)
   const int npf = NP == 2 ? prefetch_kind(p.pf) : 0;
   if constexpr (NP == 2) {
     if (npf == 1) MSD_LAUNCH_PF(1);
@@ -1224,7 +1286,7 @@ inline hipError_t launch_gemm_h16_dual(const GemmParams& p1, const Epi1& e1, Gem
   p2.pf = p1.pf;
   p2.pf_nblk = n2;
   if (NP == 2 && prefetch_kind(p1.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
   else
     hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
   return hipGetLastError();
@@ -1263,7 +1325,7 @@ inline hipError_t launch_gemm_h16_splitk(const GemmParams& p, const Epi& epi, hi
   if (attr != hipSuccess) return attr;
   const int grid = (p.M / BM) * (p.N / BN) * SK;   // = 8 XCDs x tiles per XCD x SK
   if (prefetch_kind(p.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>), dim3(grid), dim3(256), smem, stream, p, epi);
+    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>), dim3(grid), dim3(256 + pf_threads(1)), smem, stream, p, epi);
   else
     hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 0>), dim3(grid), dim3(256), smem, stream, p, epi);
   return hipGetLastError();
