@@ -63,6 +63,8 @@ typedef enum msd_precision {
   MSD_PREC_F16 = 0,    /* one IEEE-half plane per operand (v_mfma_f32_*_f16), fp32 accumulate: fast, not parity-grade */
   MSD_PREC_F16X3 = 1,  /* operands split hi + lo half planes (22 significand bits), 3 MFMAs per product
                           (hi.hi + hi.lo + lo.hi): float32-class results -- the parity mode and the default.
+                          In the decoder's attentions the QUERY side (Q in q.k^T, the softmax weights in P.V)
+                          enters as one plane, the memory side (K, V) as hi + lo: 2 MFMAs per product there.
                           Weights must satisfy |w| < 128 (packed times 2^9; checked by msd_finalize_weights ->
                           MSD_ERR_UNSUPPORTED); activations |x| <= 65504 (checked on every conversion ->
                           MSD_ERR_RANGE from the call that saw it). */
@@ -233,6 +235,12 @@ int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev,
 int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
                      const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
                      int heads, void* stream); /* q [n_q, heads*64] (n_q % 64 == 0), k/v [n_keys, heads*64] (n_keys % 32 == 0) */
+/* The same with the query-side single-plane switches of the two-plane modes: qp bit 0 = Q enters q.k^T as ONE
+ * 16-bit plane, bit 1 = the softmax weights enter P.V as one plane (K and V always keep hi + lo).  The decoder's
+ * attentions run with qp = 3 under MSD_PREC_F16X3; msd_op_attention is qp = 0. */
+int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* k_dev,
+                        const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
+                        int heads, void* stream);
 
 
 /* Standalone forms of the FUSED kernels of the step (each restates one reference function and has its

@@ -95,8 +95,8 @@ constexpr int attention_smem() {
 // (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
 // Bit 2: the queries are un-normalised, see AttnParams::q_ssq.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
-__global__ void __launch_bounds__(QB * kAttKG * 64 + pf_threads(PF)) attention_kernel(AttnParams p) {
-  if constexpr (kPfWave && PF != kPfNone) {
+__global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
+  if constexpr (kPfWaveAttn && PF != kPfNone) {
     if (threadIdx.x >= QB * kAttKG * 64) {   // the prefetch wave
       const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
       prefetch_wave<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0]);
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + pf_threads(PF)) attention_k
   PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_h16.h WeightPrefetch)
   {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if constexpr (!kPfWave) prefetch_weights<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], pf_keep);
+    if constexpr (!kPfWaveAttn) prefetch_weights<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], pf_keep);
   }
 
   // ---- merge the 4 key-group partials of each query block through LDS --------------
@@ -459,10 +459,10 @@ inline void launch_attention_qp(const AttnParams& p, int heads, int segs, hipStr
   const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
   if (blocks64 < 128) {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW, QP>), g1, dim3(kAttKG * 64 + pf_threads(PFW)), smem1, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW, QP>), g1, dim3(kAttKG * 64 + (kPfWaveAttn && PFW ? 64 : 0)), smem1, stream, p);
     else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone, QP>), g1, dim3(kAttKG * 64), smem1, stream, p);
   } else {
-    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, PFW, QP>), g2, dim3(2 * kAttKG * 64 + pf_threads(PFW)), smem2, stream, p);
+    if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 2, PFW, QP>), g2, dim3(2 * kAttKG * 64 + (kPfWaveAttn && PFW ? 64 : 0)), smem2, stream, p);
     else hipLaunchKernelGGL((attention_kernel<NP, NS, 2, kPfNone, QP>), g2, dim3(2 * kAttKG * 64), smem2, stream, p);
   }
 }

@@ -125,12 +125,19 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 #ifndef MSD_PF_WAVE
 #define MSD_PF_WAVE 0   // build-time choice between the two prefetch mechanisms (A/B: tools/ab/r03_call4.sh)
 #endif
-constexpr bool kPfWave = MSD_PF_WAVE != 0;
+constexpr bool kPfWave = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 2;       // GEMM launches (2: only those)
+constexpr bool kPfWaveAttn = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 3;   // attention launches (3: only those)
 template <int PF>
 __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk, int nblk, const void* valid) {
   if constexpr (PF != kPfNone) {
     constexpr int TOUCHES = 4 * kPrefetchPerThread;
     const int lane = (int)threadIdx.x & 63;
+    // ONE destination register for every touch, read-write in each asm statement and kept live to the end of the
+    // wave: the compiler believes an asm output is complete when the statement ends, so a register it were free to
+    // reuse (e.g. for the next address -- it did: `global_load_dword v2, v[2:3]` followed by a new address in
+    // v[2:3], overwritten by the returning load: a memory fault on the MI355X) must not exist.  Several loads
+    // in flight to the same register are harmless: nobody reads it.
+    uint32_t sink = 0;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
       const PrefetchTarget& t = pf.t[k];
@@ -146,10 +153,10 @@ __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk,
         const char* row_ptr = t.base[pl] + (size_t)row0 * t.row_stride;
         const bool in = rp0 < rows * planes && row0 + sub < rows && line < lpr;
         const char* src = in ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
-        uint32_t sink;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
+        asm volatile("global_load_dword %0, %1, off ; msd_prefetch" : "+v"(sink) : "v"(src) : "memory");
       }
     }
+    asm volatile("" ::"v"(sink));
   }
 }
 

@@ -169,7 +169,12 @@ struct msd_model {
   // two-plane mode, one cross-attention module and D % 128 == 0
   bool hoist_q = true;
   Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
-  // query-side single-plane attention (attention.h QP; MSD_ATT_QP_SELF / MSD_ATT_QP_CROSS = 0..3, decoder only)
+  // Query-side single-plane attention of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q, 2 = P).
+  // Default 3 with half planes in the two-plane mode: 11-bit Q and P planes against K / V kept as hi + lo cost
+  // 1.05 - 1.25x the float32 oracle's own error (small 1000 steps 7.4e-5 vs 6.8e-5; 12-segment chain 0.9 - 1.2x the
+  // float32 oracle at every depth: profiles/r03c_golden_qp3.log) and save 2.2 % of the step (two of six MFMAs per
+  // tile pair, no hi / lo split of P).  bfloat16 planes (8-bit significands) keep all three products: 2.7e-4 there.
+  // MSD_ATT_QP_SELF / MSD_ATT_QP_CROSS = 0..3 override.
   int att_qp_self = 0, att_qp_cross = 0;
   // split-K MLP output projection (gemm_h16.h gemm_h16_splitk_kernel).  OFF by default: measured 2.5 % SLOWER per
   // step than the 64 x 32 tiles on the MI355X (profiles/r03b_env_ab.log: 1168 vs 1140 ms per segment; the exchange
@@ -1362,6 +1367,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
   if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
+  m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;
   if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
   if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
   if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
@@ -1958,6 +1964,12 @@ int msd_op_gemm_f32(const float* a_dev, const float* w_dev, float* c_dev, int M,
 
 int msd_op_attention(int precision, const float* q_dev, const float* k_dev, const float* v_dev,
                      float* o_dev, int n_q, int n_keys, int n_keys_valid, int heads, void* stream) {
+  return msd_op_attention_qp(precision, 0, q_dev, k_dev, v_dev, o_dev, n_q, n_keys, n_keys_valid, heads, stream);
+}
+
+int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* k_dev, const float* v_dev,
+                        float* o_dev, int n_q, int n_keys, int n_keys_valid, int heads, void* stream) {
+  if (qp < 0 || qp > 3) return MSD_ERR_INVALID_ARGUMENT;
   if (n_q % 64 || n_keys % 32 || n_q <= 0 || n_keys <= 0 || heads <= 0 || n_keys_valid < 0 ||
       n_keys_valid > n_keys)
     return MSD_ERR_INVALID_ARGUMENT;
@@ -1994,6 +2006,7 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
   split(vt32, vt.p[0], NP == 2 ? vt.p[1] : nullptr, (int64_t)J * n_keys, s, fl.sat());
   AttnParams p;
   fl.arm(p);
+  p.qp = qp;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
     p.q[i] = q.p[j]; p.k[i] = k.p[j]; p.vt[i] = vt.p[j]; p.o[i] = o.p[j];

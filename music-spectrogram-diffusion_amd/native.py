@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
     'msd_encode', 'msd_sample', 'msd_reset_graph', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
     'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_h16', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
-    'msd_op_attention', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
+    'msd_op_attention', 'msd_op_attention_qp', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
     'msd_op_qkv', 'msd_op_final_proj')
 
 
@@ -140,6 +140,8 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   lib.msd_op_gemm_bf16.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_gemm_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
   lib.msd_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  if 'msd_op_attention_qp' in present:
+    lib.msd_op_attention_qp.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   lib.msd_op_sampler_step.argtypes = [c.POINTER(MsdConfig), i32, vp, vp, vp, vp, vp, i64, vp]
   lib.msd_op_residual_norm_gemm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   lib.msd_op_geglu.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
@@ -329,12 +331,13 @@ def op_gemm_f32(a, w, c, stream: int = 0):
 
 
 def op_attention(precision: str, q, k, v, o, heads: int, n_keys_valid: Optional[int] = None,
-                 stream: int = 0):
+                 stream: int = 0, qp: int = 0):
+  """qp: query-side single-plane switches (bit 0: Q, bit 1: P); the decoder runs 'f16x3' with qp = 3."""
   lib = load(plane_format(precision))
   n_q, n_keys = q.shape[0], k.shape[0]
   nv = n_keys if n_keys_valid is None else n_keys_valid
-  rc = lib.msd_op_attention(PRECISIONS[precision], _ptr(q), _ptr(k), _ptr(v), _ptr(o), n_q,
-                            n_keys, nv, heads, stream)
+  rc = lib.msd_op_attention_qp(PRECISIONS[precision], qp, _ptr(q), _ptr(k), _ptr(v), _ptr(o), n_q,
+                               n_keys, nv, heads, stream)
   if rc:
     raise _EXC.get(rc, RuntimeError)('msd_op_attention failed (%d)' % rc)
 

@@ -86,6 +86,8 @@ F16_VARIANTS = {
     'f16_noqplo': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
     'f16_noqplo_self': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
     'f16_noqplo_cross': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noqplo_dec': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
+    'f16_noqlo_dec': dict(scale_w=True, mm=[(0, 0), (0, 1), (1, 0)]),
 }
 
 # half planes, query-side lo planes of ATTENTION dropped: name -> (QK products, PV products, where)
@@ -94,6 +96,8 @@ _NOL = [(0, 0), (0, 1)]          # left operand (Q resp. P) single plane
 F16_ATT = {
     'f16_noqlo': (_NOL, _X3, 'all'), 'f16_noplo': (_X3, _NOL, 'all'), 'f16_noqplo': (_NOL, _NOL, 'all'),
     'f16_noqplo_self': (_NOL, _NOL, 'self'), 'f16_noqplo_cross': (_NOL, _NOL, 'cross'),
+    # what the device does since round 3 (attention.h QP = 3 on the DECODER's two attentions; encoders keep all planes)
+    'f16_noqplo_dec': (_NOL, _NOL, 'dec'), 'f16_noqlo_dec': (_NOL, _X3, 'dec'),
 }
 
 
@@ -170,6 +174,13 @@ class StudyModel(fast.FastModel):
       y = y + self.xp.matmul(a_parts[a], w_parts[b])
     return y
 
+  def decoder_pass(self, z, i, cond):
+    self._in_decoder = True
+    try:
+      return super().decoder_pass(z, i, cond)
+    finally:
+      self._in_decoder = False
+
   def _attend(self, q, k, v):
     xp = self.xp
     qk, pv = VARIANTS.get(self.variant, VARIANTS['x3'])
@@ -178,7 +189,8 @@ class StudyModel(fast.FastModel):
       # decoder self-attention has as many keys as queries (and encoder self-attention too); cross-attention
       # is the only call with a different key count on these configs
       is_self = q.shape[0] == k.shape[0]
-      if (where == 'self' and not is_self) or (where == 'cross' and is_self):
+      if (where == 'self' and not is_self) or (where == 'cross' and is_self) or (
+          where == 'dec' and not getattr(self, '_in_decoder', False)):
         qk, pv = _X3, _X3
     def split(a):
       if self.variant in F16_VARIANTS:

@@ -138,6 +138,15 @@ def test_attention(env, prec, tol, nq, nk, valid, heads):
   ref = ops.dot_product_attention(xp, sh(q, nq), sh(k[:valid], valid), sh(v[:valid], valid))
   ref = ref.reshape(nq, j)
   assert np.abs(got - ref).max() < tol * max(1.0, np.abs(ref).max())
+  if prec == 'f16x3':
+    # the decoder's form of this mode: Q and the softmax weights as ONE half plane each (11 significand bits), K / V
+    # as hi + lo.  Bounds: the logits move by |s| 2^-12 ~ 1e-3 at |s| ~ 4, so the weights by ~1e-3 relative, and
+    # rounding the weights themselves adds 2^-12 -- a few 1e-4 of the output range (single-plane 'f16' is 5e-3)
+    for qp, bound in ((1, 6e-4), (2, 3e-4), (3, 8e-4)):
+      o.zero_()
+      native.op_attention(prec, _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads, n_keys_valid=valid, qp=qp)
+      err = np.abs(o.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+      assert err < bound, (qp, err)
 
 
 def test_attention_spiked_key_forces_online_rescale(env):

@@ -52,6 +52,7 @@ for s, ii in by_func.items():
         seen.add(j)
         l = lines[j].split(';')[0].strip()
         op = l.split(None, 1)[0] if l else ''
+        # (another tagged touch into the same register is not a hazard: nobody reads these registers)
         if writes(lines[j], r) and not ('global_load_dword v%d,' % r in l and 'ASMSTART' in lines[j - 1]):
           hit = j
           break
