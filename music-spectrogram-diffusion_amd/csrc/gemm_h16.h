@@ -46,6 +46,11 @@ struct PrefetchTarget {
   int row_stride = 0;      // bytes between rows
   int lpr = 0;             // 128-byte lines to touch per row (<= 64)
   int lg = 0;              // log2 of the line slots per row (host: smallest power of two >= lpr)
+  // optional device-side bound, read by the prefetch wave: the cached cross-attention K / V^T of a segment are
+  // valid up to n_keys only.  dyn_mode 1: rows = min(rows, *dyn) (K: one row per key); 2: the row length is
+  // min(row bytes, *dyn * 2) (V^T: one 16-bit column per key)
+  const int* dyn = nullptr;
+  int dyn_mode = 0;
   void set(const void* p0, const void* p1, int rows_, int row_stride_, int row_bytes) {
     base[0] = static_cast<const char*>(p0); base[1] = static_cast<const char*>(p1);
     rows = rows_; row_stride = row_stride_; lpr = (row_bytes + 127) >> 7;
@@ -123,8 +128,8 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 // time to arrive before their consumer starts.  An ended wave no longer counts at s_barrier, so the compute
 // waves' barriers are unaffected once it has gone.  One wave issues what the four compute waves issued together.
 #ifndef MSD_PF_WAVE
-#define MSD_PF_WAVE 0   // build-time choice between the two prefetch mechanisms (A/B: tools/ab/r03_call4.sh)
-#endif
+#define MSD_PF_WAVE 1   // 1: prefetch wave (default since round 3: -1.0 % step time same-box, profiles/r03f_env_ab.log);
+#endif                  // 0: the round-2 in-epilogue touches (kept buildable for A/B runs: -DMSD_PF_WAVE=0)
 constexpr bool kPfWave = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 2;       // GEMM launches (2: only those)
 constexpr bool kPfWaveAttn = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 3;   // attention launches (3: only those)
 template <int PF>
@@ -141,7 +146,12 @@ __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk,
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
       const PrefetchTarget& t = pf.t[k];
-      const int rows = t.rows, lpr = t.lpr;
+      int rows = t.rows, lpr = t.lpr;
+      if (t.dyn_mode != 0) {
+        const int nkeys = *t.dyn;
+        if (t.dyn_mode == 1) rows = nkeys < rows ? nkeys : rows;
+        else { const int l2 = (nkeys * 2 + 127) >> 7; lpr = l2 < lpr ? l2 : lpr; }
+      }
       const int planes = t.base[1] && t.base[1] != t.base[0] ? 2 : 1;
       const int rpt = 64 >> t.lg;
       const int sub = lane >> t.lg, line = lane & ((1 << t.lg) - 1);

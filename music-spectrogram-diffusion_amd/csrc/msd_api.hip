@@ -161,6 +161,7 @@ struct msd_model {
   // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
   bool chain_mlp = false;
   bool prefetch = true;        // producers warm the next GEMM's weights in L2 (MSD_PREFETCH=0: off)
+  bool pf_kv = true;           // prefetch-wave builds: the QKV launch also warms the layer's cached cross-attention K / V^T (MSD_PF_KV=0: off)
   int cus = 0;                 // compute units of the device (chain grid = one block per CU)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
@@ -1077,7 +1078,20 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     const bool last_layer = (l + 1 == m->Ld);
     if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
-      const WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
+      WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
+      // The layer's cached cross-attention K and V^T (14 MB at base, HBM-cold at every step: nothing touched
+      // them since the previous step) ride on this launch's prefetch waves, three launches ahead of their
+      // consumer.  With the in-epilogue prefetch the same idea cost the producer 3 us and won 1;
+      // from a wave of its own it costs the producer nothing.  Bounded by the segment's key count on the device.
+      if (kPfWave && m->prefetch && m->pf_kv && cond0 && NP == 2 && batch == 1 && m->n_cross == 1 && row0 == 0) {
+        const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
+        PrefetchTarget tk, tv;
+        tk.set(m->kc.p[0] + loff, m->kc.p[1] + loff, m->S_pad, J * 2, J * 2);
+        tk.dyn = m->d_nkeys_cross; tk.dyn_mode = 1;
+        tv.set(m->vtc.p[0] + loff, m->vtc.p[1] + loff, J, m->S_pad * 2, m->S_pad * 2);
+        tv.dyn = m->d_nkeys_cross; tv.dyn_mode = 2;
+        if (tv.lpr <= 64) { pf.add(tk); pf.add(tv); }
+      }
       gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
@@ -1366,6 +1380,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
   if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
   if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
+  if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
   m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;
   if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
