@@ -161,7 +161,11 @@ struct msd_model {
   // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
   bool chain_mlp = false;
   bool prefetch = true;        // producers warm the next GEMM's weights in L2 (MSD_PREFETCH=0: off)
-  bool pf_kv = true;           // prefetch-wave builds: the QKV launch also warms the layer's cached cross-attention K / V^T (MSD_PF_KV=0: off)
+  // prefetch-wave builds: the QKV launch also warms the layer's cached cross-attention K / V^T.  OFF: measured +2.5 %
+  // step time on the MI355X (profiles/r03g_env_ab.log: 1099-1105 vs 1073-1075 ms per segment): cross-attention wins
+  // 1 us, but the QKV launch loses 2.2 -- its compute waves' first s_barrier also waits for the prefetch wave, whose 36
+  // touches take longer to retire than the first K-tile takes to land.  MSD_PF_KV=1 turns it on.
+  bool pf_kv = false;
   int cus = 0;                 // compute units of the device (chain grid = one block per CU)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
@@ -1364,6 +1368,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->n_dims % 64) return bad("n_dims must be a multiple of 64");
   if (cfg->num_steps <= 0 || cfg->max_batch <= 0 || cfg->num_heads <= 0) return bad("non-positive size");
   if (cfg->has_context && cfg->context_length <= 0) return bad("context model needs context_length");
+  if (cfg->attn_query_planes < 0 || cfg->attn_query_planes > 2) return bad("attn_query_planes must be 0 (library default), 1 or 2");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1383,6 +1388,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
   m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;
+  if (cfg->attn_query_planes == 2) m->att_qp_self = m->att_qp_cross = 0;
+  else if (cfg->attn_query_planes == 1 && m->NP == 2) m->att_qp_self = m->att_qp_cross = 3;
   if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
   if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
   if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);

@@ -72,7 +72,7 @@ MODEL_OUTPUTS = {'eps': MSD_OUTPUT_EPS, 'x0': MSD_OUTPUT_X0, 'v': MSD_OUTPUT_V}
 
 
 class MsdConfig(ctypes.Structure):
-  """msd_config of include/msd_amd.h (ABI 2), field for field."""
+  """msd_config of include/msd_amd.h (ABI 3), field for field."""
   _fields_ = [(n, ctypes.c_int32) for n in (
       'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
       'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
@@ -84,7 +84,8 @@ class MsdConfig(ctypes.Structure):
       ('sampler_schedule', ctypes.c_int32), ('sampler_schedule_start', ctypes.c_float),
       ('sampler_schedule_stop', ctypes.c_float), ('train_schedule', ctypes.c_int32),
       ('train_schedule_start', ctypes.c_float), ('train_schedule_stop', ctypes.c_float),
-      ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32)]
+      ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32),
+      ('attn_query_planes', ctypes.c_int32)]
 
 
 _libs = {}

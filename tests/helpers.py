@@ -64,6 +64,17 @@ def rms(a, b):
   return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
+# Short DDPM chains (3 - 8 huge steps) are ill-conditioned amplifiers: assert_fp32_class below can tell float32-class
+# arithmetic from anything coarser.  The product's default 'f16x3' mode keeps hi + lo planes everywhere EXCEPT the
+# query side of the decoder's attentions (Q and the softmax weights as one half plane), which is a
+# deliberate, measured step off that class on single passes (1.0e-4 .. 1.2e-4 max relative error instead of 5e-5 ..
+# 9e-5) that the 1000-step results do not show (1.05 - 1.25x the float32 oracle).  So: the short-chain statistics and
+# the bit-for-bit / 1e-5 A-B comparisons run on models built with ALL_PLANES (every product hi.hi + hi.lo + lo.hi),
+# single decoder passes run in BOTH modes against the same 2e-4 / 3e-4 bounds, and the 1000-step goldens and the
+# chain-depth test run in the default mode against north_star's bars.
+ALL_PLANES = dict(attention_query_planes=2)
+
+
 def assert_fp32_class(got, ref64, ref32, what=''):
   """Short DDPM chains are ill-conditioned by construction: at the first step
   (t = 1, logsnr = -20) x0 = 22026 (z - eps) is clipped to +-1 for all but a few

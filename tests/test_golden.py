@@ -33,7 +33,7 @@ def test_tiny_golden_on_device():
   params = msd_amd.synthetic.init_params(spec, int(g['weight_seed']), norm_scale_jitter=float(g['jitter']))
   batch = helpers.make_batch(spec, batch=2, seed=int(g['batch_seed']), ctx_mask='ragged')
   init_z, noise = helpers.make_noise(spec, batch=2, seed=int(g['noise_seed']))
-  model = msd_amd.InferenceModel(params, spec, batch_size=2)
+  model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
   got, _ = model.predict(batch, init_z=init_z, noise=noise)
   # 6 huge steps are ill-conditioned (helpers.assert_fp32_class): the yardstick is the float32 oracle's
   # own deviation from the float64 fixture, on the bulk, on the outlier count AND on the rms (x3)

@@ -30,7 +30,7 @@ def tiny_ctx():
   assert torch.cuda.is_available()
   spec = msd_amd.config.preset('tiny_context', num_steps=6)
   params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
-  model = msd_amd.InferenceModel(params, spec, batch_size=2)
+  model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)   # short-chain statistics: helpers.ALL_PLANES
   return spec, params, model
 
 
@@ -72,10 +72,21 @@ def test_film_table_matches_oracle(tiny_ctx):
     assert worst < tol
 
 
+@pytest.fixture(scope='module')
+def tiny_ctx_default(tiny_ctx):
+  """The same model in the product's DEFAULT attention mode (query side of the decoder's attentions as one half
+  plane); `tiny_ctx` runs all planes for the short-chain statistics (helpers.ALL_PLANES)."""
+  spec, params, _ = tiny_ctx
+  return msd_amd.InferenceModel(params, spec, batch_size=2)
+
+
+@pytest.mark.parametrize('attention', ['all planes', 'default'])
 @pytest.mark.parametrize('mask', ['ones', 'zeros', 'ragged'])
-def test_encode_and_single_decoder_pass(tiny_ctx, mask):
+def test_encode_and_single_decoder_pass(tiny_ctx, tiny_ctx_default, mask, attention):
   import torch
   spec, params, model = tiny_ctx
+  if attention == 'default':
+    model = tiny_ctx_default
   nm = model._get_native()
   batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)
   ref_out, fm = None, None
@@ -134,7 +145,7 @@ def test_cfg_weight_one_and_ddim_and_no_context_model():
   for preset, kw in [('tiny_context', dict(cfg_weight=1.0)), ('tiny', dict(cfg_weight=5.0))]:
     spec = msd_amd.config.preset(preset, num_steps=5, **kw)
     params = msd_amd.synthetic.init_params(spec, 9, norm_scale_jitter=0.1)
-    model = msd_amd.InferenceModel(params, spec)
+    model = msd_amd.InferenceModel(params, spec, **helpers.ALL_PLANES)
     batch = helpers.make_batch(spec)
     init_z, noise = helpers.make_noise(spec)
     got, _ = model.predict(batch, init_z=init_z, noise=noise)
@@ -148,7 +159,7 @@ def test_cfg_weight_one_and_ddim_and_no_context_model():
   spec = dataclasses.replace(spec, diffusion=dataclasses.replace(
       d, sampler=dataclasses.replace(d.sampler, name='ddim')))
   params = msd_amd.synthetic.init_params(spec, 9)
-  model = msd_amd.InferenceModel(params, spec)
+  model = msd_amd.InferenceModel(params, spec, **helpers.ALL_PLANES)
   batch = helpers.make_batch(spec)
   init_z, _ = helpers.make_noise(spec)
   got, _ = model.predict(batch, init_z=init_z)
@@ -257,7 +268,7 @@ def test_batched_songs_use_big_tiles_and_match_oracle():
   spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, emb_dim=192, num_heads=3))
   params = msd_amd.synthetic.init_params(spec, 5, norm_scale_jitter=0.1)
   B = 16
-  model = msd_amd.InferenceModel(params, spec, batch_size=B)
+  model = msd_amd.InferenceModel(params, spec, batch_size=B, **helpers.ALL_PLANES)
   batch = helpers.make_batch(spec, batch=B, ctx_mask='ragged')
   init_z, noise = helpers.make_noise(spec, batch=B)
   got, _ = model.predict(batch, init_z=init_z, noise=noise)
@@ -290,7 +301,7 @@ def test_midi_in_synthesis(tiny_ctx, tmp_path):
   base = tiny_ctx[0]                        # tiny shapes, but the real 1536-entry MT3 vocabulary
   spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, vocab_size=1536))
   params = msd_amd.synthetic.init_params(spec, 4, norm_scale_jitter=0.1)
-  model = msd_amd.InferenceModel(params, spec)
+  model = msd_amd.InferenceModel(params, spec, **helpers.ALL_PLANES)
   ns = note_sequences.NoteSequence()
   for k, (p, prog) in enumerate([(60, 0), (64, 0), (67, 40), (72, 40), (55, 0)]):
     ns.add_note(pitch=p, velocity=90, start_time=0.3 * k, end_time=0.3 * k + 1.1, program=prog)
@@ -335,7 +346,7 @@ def test_key_split_cross_attention_edge_lengths(valid):
   base = msd_amd.config.preset('tiny_context', num_steps=3)
   spec = dataclasses.replace(base, task_feature_lengths={'inputs': 1024, 'targets': 64, 'targets_context': 64})
   params = msd_amd.synthetic.init_params(spec, 6, norm_scale_jitter=0.1)
-  model = msd_amd.InferenceModel(params, spec)
+  model = msd_amd.InferenceModel(params, spec, **helpers.ALL_PLANES)
   nm = model._get_native()
   cfg, dc = helpers.oracle_configs(spec)
   z = np.random.default_rng(0).standard_normal((1, 64, 128)).astype(np.float32)
@@ -370,7 +381,7 @@ def test_xcd_resident_chain_kernel_matches_separate_launches(monkeypatch):
   outs, eps = {}, {}
   for chain in ('0', '1'):
     monkeypatch.setenv('MSD_CHAIN', chain)
-    model = msd_amd.InferenceModel(params, spec, batch_size=2)
+    model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
     outs[chain], _ = model.predict(batch, init_z=init_z, noise=noise)
     nm = model._get_native()
     z = torch.as_tensor(init_z).cuda()
@@ -409,7 +420,7 @@ def test_hoisted_cross_query_projection_matches_the_plain_order(monkeypatch, pre
   outs, eps = {}, {}
   for hoist in ('0', '1'):
     monkeypatch.setenv('MSD_HOIST_Q', hoist)
-    model = msd_amd.InferenceModel(params, spec, batch_size=2)
+    model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
     outs[hoist], _ = model.predict(batch, init_z=init_z, noise=noise)
     nm = model._get_native()
     z = torch.as_tensor(init_z).cuda()
@@ -442,7 +453,7 @@ def test_sum_cross_attends_style(preset, mask):
   spec = msd_amd.config.preset(preset, num_steps=6)
   spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style='sum_cross_attends'))
   params = msd_amd.synthetic.init_params(spec, 8, norm_scale_jitter=0.1)
-  model = msd_amd.InferenceModel(params, spec, batch_size=2)
+  model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
   nm = model._get_native()
   batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)
   cfg, dc = helpers.oracle_configs(spec)
