@@ -506,6 +506,11 @@ def main():
       if launches:
         per_class[name] = {'ms_per_launch': ms / launches, 'launches_per_step': launches / args.profile_steps,
                            'ms_per_step': ms / args.profile_steps}
+    if 'gemm_cross_q' not in per_class and 'gemm_attn_out' in per_class:
+      # hoisted query projection (csrc/msd_api.hip decoder_layers): the cross-attention q GEMM runs inside the
+      # self-attention output projection's launch -- its ALGORITHMIC work (2 T J D, once) is counted there
+      flops['gemm_attn_out'] += flops['gemm_cross_q']
+      abytes['gemm_attn_out'] += abytes.get('gemm_cross_q', 0)
     # dominant kernel = the longest single launch of the step (the class whose template also has
     # the most algorithmic FLOPs); per-step totals by class are listed in per_class_ms_per_step
     dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_launch'])

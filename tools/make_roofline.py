@@ -28,12 +28,17 @@ import msd_amd  # noqa: E402
 
 CLOCK_GHZ = 2.4      # MI355X peak engine clock (MI355X_MICROARCH.md); SQ cycle counters tick at the engine clock
 SIMDS = 256 * 4
-# (substring of the demangled kernel name, class) -- first match wins
+# (substring of the demangled kernel name, class) -- first match wins.  Round 3 renamed the 16-bit-plane kernels
+# (gemm_bf16_* -> gemm_h16_*, EpiStoreBf16 -> EpiStoreH16) and added the dual launch of the hoisted query projection;
+# the round-2 names stay so that the committed r02 traces still classify.
 CLASS = [
+    ('gemm_h16_dual_kernel', 'gemm_attn_out+cross_q'),      # self-attention output projection + hoisted cross-attention q
+    ('gemm_h16_splitk_kernel', 'gemm_mlp_out'),
     ('EpiGeglu', 'gemm_mlp_in_geglu'), ('EpiQKV', 'gemm_qkv'),
     ('64, 32, 4, msd::EpiResidualNorm', 'gemm_mlp_out'), ('64, 32, 4, EpiResidualNorm', 'gemm_mlp_out'),
     ('32, 32, 4, msd::EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'), ('32, 32, 4, EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'),
     ('32, 32, 4, msd::EpiStoreBf16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreBf16', 'gemm_cross_q'),
+    ('32, 32, 4, msd::EpiStoreH16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreH16', 'gemm_cross_q'),
     ('attention_merge_kernel', 'attn_cross_merge'),
     ('attention_kernel<2, 2, 1', 'attn_self'), ('attention_kernel<2, 2, 2', 'attn_cross'),
     ('final_proj_f32_kernel', 'final_proj_f32'), ('EpiInProj', 'in_proj_f32'), ('sampler_step_kernel', 'sampler_step'),
@@ -60,6 +65,10 @@ def main():
   # the shared 32x32 residual template serves two classes with different M: weight by launch share (1:1)
   flops['gemm_attn_out+gemm_cross_out'] = 0.5 * (flops['gemm_attn_out'] + flops['gemm_cross_out'])
   abytes['gemm_attn_out+gemm_cross_out'] = 0.5 * (abytes['gemm_attn_out'] + abytes['gemm_cross_out'])
+  # hoisted query projection (round 3): one launch = the out-projection (M = 2T) + [x (.) gamma | ao] . [Wq ; Wo g Wq]
+  # (M = T, K = D + J); with it the 32 x 32 residual template only serves the cross-attention output projection
+  flops['gemm_attn_out+cross_q'] = flops['gemm_attn_out'] + flops['gemm_cross_q']          # ALGORITHMIC: 2 T J D once
+  abytes['gemm_attn_out+cross_q'] = abytes['gemm_attn_out'] + abytes['gemm_cross_q']
   flops.setdefault('attn_cross_merge', 0.0)
   flops.setdefault('sampler_step', 0.0)
   # a class may run as several instantiations (with / without the weight prefetch): call-weighted means
@@ -114,7 +123,16 @@ def main():
         e['waste'] = round(fb / ab, 2)
   sha_path = os.path.join(prof, '%s_library_sha.txt' % tag)
   sha = open(sha_path).read().strip() if os.path.exists(sha_path) else 'unknown (%s predates the stamp)' % tag
-  launches = {'gemm_attn_out+gemm_cross_out': 24, 'final_proj_f32': 1, 'in_proj_f32': 1, 'sampler_step': 1}
+  hoisted = 'gemm_attn_out+cross_q' in out
+  if hoisted and 'gemm_attn_out+gemm_cross_out' in out:   # that template now runs the cross-attention output projection only
+    e = out['gemm_attn_out+gemm_cross_out']
+    e['algorithmic_gflop'] = round(flops['gemm_cross_out'] / 1e9, 4)
+    e['tflops'] = round(flops['gemm_cross_out'] / (e['avg_us'] * 1e-6) / 1e12, 2)
+    e['frac'] = round(e['tflops'] / bench.PEAK_BF16_TFLOPS, 5)
+    if 'fabric_bytes_per_launch' in e:
+      e['algorithmic_bytes'] = int(abytes['gemm_cross_out'])
+      e['waste'] = round(e['fabric_bytes_per_launch'] / abytes['gemm_cross_out'], 2)
+  launches = {'gemm_attn_out+gemm_cross_out': 12 if hoisted else 24, 'final_proj_f32': 1, 'in_proj_f32': 1, 'sampler_step': 1}
   step_us = sum(e['avg_us'] * launches.get(c, 12) for c, e in out.items())
   step_fabric = sum(e.get('fabric_bytes_per_launch', 0) * launches.get(c, 12) for c, e in out.items())
   step_alg = sum(e.get('algorithmic_bytes', 0) * launches.get(c, 12) for c, e in out.items())
