@@ -650,12 +650,13 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_splitk_kernel(G
   gemm_tile<NP, BM, BN, NS, Epi, 0, PF, SK>(p, epi, bm, bn, smem, ks, bm * nbn + bn);
 }
 
-// Two independent GEMMs of one tile shape in ONE launch (no data flows between them): blocks [0, n2) run problem 2,
-// whose A operand is K-concatenated (DA), the rest problem 1.  Used for the self-attention output projection
-// together with the HOISTED cross-attention query projection (msd_api.hip decoder_layers): a launch boundary less
-// per layer, and the longer K loop starts first.  Each problem keeps its own XCD-aware tile map (n2 is a multiple
-// of 8, so a block's XCD is the same in the launch-wide and in the problem-local numbering).
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone>
+// Two independent GEMMs of one tile shape in ONE launch (no data flows between them): blocks [0, n2) run problem 2
+// (optionally with a K-concatenated A operand, DA2), the rest problem 1.  Used by the HOISTED cross-attention query
+// projection (msd_api.hip decoder_layers): its first half rides on the QKV launch's idle CUs, its second half on the
+// launch of the self-attention output projection -- a launch boundary less per layer.  Each problem keeps its own
+// XCD-aware tile map (n2 is a multiple of 8, so a block's XCD is the same in the launch-wide and in the
+// problem-local numbering).
+template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone, int DA2 = 0>
 __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (kPfWave && PF != kPfNone) {
@@ -678,17 +679,15 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(Gem
     bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
   }
   if (bn >= nbn || bm >= nbm) return;
-  // the weight prefetch rides on problem 1's blocks only (two thirds of the launch): ONE prefetch site in the
-  // kernel, behind which nothing but that arm's epilogue runs (tools/check_prefetch_regs.py follows the control flow)
-  // The weight prefetch rides on problem 2's blocks only (the first n2 of the launch; p2.pf_nblk = n2): ONE prefetch
-  // site in the kernel, in the arm behind which nothing but its own epilogue runs -- tools/check_prefetch_regs.py
-  // follows the control flow, and the structurised two-arm layout of this kernel re-tests its condition after
-  // the first arm, which no text tool can see through.
+  // In-epilogue prefetch builds (MSD_PF_WAVE=0): the touches ride on problem 2's blocks only (p2.pf_nblk = n2): ONE
+  // prefetch site in the kernel, in the arm behind which nothing but its own epilogue runs --
+  // tools/check_prefetch_regs.py follows the control flow, and the structurised two-arm layout of this kernel
+  // re-tests its condition after the first arm, which no text tool can see through.
   if (!second) {
     gemm_tile<NP, BM, BN, NS, Epi1, 0, kPfNone>(p1, e1, bm, bn, smem);
     return;
   }
-  gemm_tile<NP, BM, BN, NS, Epi2, 0, PF, 1, 1>(p2, e2, bm, bn, smem);
+  gemm_tile<NP, BM, BN, NS, Epi2, 0, PF, 1, DA2>(p2, e2, bm, bn, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -855,6 +854,53 @@ struct EpiStoreH16 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
       }
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
+    }
+    rc.commit(sf.p, sf.tag);
+  }
+};
+
+// C (row-major 16-bit planes) = acc + addend[m][n] (fp32): the second half of the hoisted cross-attention query
+// projection adds the first half, which an earlier launch left in float32.  The addend tile is prefetched into the
+// aux LDS region like the residual tile of EpiResidualNorm (BN == 32), so the epilogue issues no global load.
+template <int NP>
+struct EpiAddStoreH16 {
+  h16_t* out[2];
+  int ldc;
+  const float* addend;
+  int ld_add;
+  template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 : 0; }
+  template <int BM, int BN, int CP = 0>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    if (BN != 32) return;
+    __builtin_assume(aux != nullptr);
+    for (int i = wave; i < BM / 8; i += 4)
+      __builtin_amdgcn_global_load_lds(
+          (aux_gptr_t)(addend + (size_t)(m0 + 8 * i + (lane >> 3)) * ld_add + n0 + (lane & 7) * 4),
+          (aux_lptr_t)(aux + i * 1024), 16, 0, CP);
+  }
+  template <int BM, int LD>
+  __device__ void stats(float*, int, int, const char*) const {}
+  template <int BM, int BN, int LD>
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
+    const bool pre = aux && BN == 32;
+    typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
+    RangeCheck rc;
+    for (int item = tid; item < BM * BN / 8; item += 256) {
+      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+      float v[8];
+      tile_row8<LD>(s0, m, n, v);
+      f32x4 a, b;
+      if (pre) {
+        lds_cf32x4 xs = (lds_cf32x4)(aux);
+        a = xs[(m * BN + n) / 4]; b = xs[(m * BN + n) / 4 + 1];
+      } else {
+        const float* pa = addend + (size_t)(m0 + m) * ld_add + n0 + n;
+        a = *reinterpret_cast<const f32x4*>(pa); b = *reinterpret_cast<const f32x4*>(pa + 4);
+      }
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
       store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
     }
     rc.commit(sf.p, sf.tag);
@@ -1278,13 +1324,13 @@ constexpr int gemm_h16_dual_smem() {
   constexpr int a = gemm_h16_dma_smem<NP, BM, BN, NS, Epi1>(), b = gemm_h16_dma_smem<NP, BM, BN, NS, Epi2>();
   return a > b ? a : b;
 }
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
+template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int DA2>
 inline hipError_t gemm_h16_dual_prepare() {
   constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
   if (smem < 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0, DA2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>),
+  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1, DA2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return e != hipSuccess ? e : r;
 }
@@ -1292,20 +1338,20 @@ inline int gemm_grid_blocks(const GemmParams& p, int BM, int BN) {
   const int rx = p.xcd_rows, cx = 8 / rx;
   return 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
 }
-// p1 / e1: the plain problem; p2 / e2: the problem with the K-concatenated A operand (A2, lda2, k_split set).  The
-// weight prefetch target (at most one) is taken from p1.pf and touched by all blocks of the launch.
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
+// p1 / e1: the first problem; p2 / e2: the second (DA2 = 1: K-concatenated A operand, p2.A2 / lda2 / k_split set).
+// The weight prefetch target (at most one) is taken from p1.pf.
+template <int NP, int BM, int BN, int NS, int DA2, class Epi1, class Epi2>
 inline hipError_t launch_gemm_h16_dual(const GemmParams& p1, const Epi1& e1, GemmParams p2, const Epi2& e2, hipStream_t stream) {
   constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
-  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM, BN, NS, Epi1, Epi2>();
+  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM, BN, NS, Epi1, Epi2, DA2>();
   if (attr != hipSuccess) return attr;
   const int n1 = gemm_grid_blocks(p1, BM, BN), n2 = gemm_grid_blocks(p2, BM, BN);
   p2.pf = p1.pf;
   p2.pf_nblk = n2;
   if (NP == 2 && prefetch_kind(p1.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1, DA2>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
   else
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0, DA2>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
   return hipGetLastError();
 }
 

@@ -70,8 +70,8 @@ struct DecLayerW {
   Planes wq_cross[2];   // [J, D]
   Planes wkv_cross[2];  // [2J, D] (k|v)
   Planes wo_cross[2];   // [D, J]
-  // hoisted query projection of module 0 (decoder_layers): W^T of [Wq ; Wo_self . diag(gamma_cross) . Wq], [J, D + J]
-  Planes wq2;
+  // hoisted query projection of module 0 (decoder_layers): W^T of Wo_self . diag(gamma_cross) . Wq, [J, J]
+  Planes w2;
   MlpW mlp;
 };
 struct EncoderW {
@@ -174,6 +174,7 @@ struct msd_model {
   // two-plane mode, one cross-attention module and D % 128 == 0
   bool hoist_q = true;
   Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
+  float* qpart = nullptr;      // (x0 (.) gamma_cross) . Wq of the layer, fp32 [Bmax * T, J]: first half of the hoisted projection
   // Query-side single-plane attention of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q, 2 = P).
   // Default 3 with half planes in the two-plane mode: 11-bit Q and P planes against K / V kept as hi + lo cost
   // 1.05 - 1.25x the float32 oracle's own error (small 1000 steps 7.4e-5 vs 6.8e-5; 12-segment chain 0.9 - 1.2x the
@@ -1080,13 +1081,23 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     // behind its own epilogue): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional
     // pass) . cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
     const bool last_layer = (l + 1 == m->Ld);
+    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1).  Its input is
+    // LN(x1) = rstd(x1) (x1 (.) gamma) with x1 = x0 + ao . Wo (x0: the stream entering the layer, ao: the
+    // self-attention output), so
+    //   (x1 (.) gamma) . Wq = (x0 (.) gamma) . Wq  +  ao . (Wo . diag(gamma) . Wq)
+    // and neither term needs the out-projection's result: the first (`qpart`, fp32) is computed by 32 extra blocks
+    // of the QKV launch, which leaves 64 of the 256 CUs idle; the second rides on the launch of the out-projection
+    // and adds the first in its epilogue (gemm_h16_dual_kernel both times); the 1/rms moves onto the logits inside
+    // the attention kernel (AttnParams::q_ssq).  The query projection's own launch (6.2 us of a 93 us layer in round 2)
+    // disappears.  x0 (.) gamma arrives as the planes `yc`, written by whichever epilogue produced x0.
+    const TileShape tq = pick_tile<NP, TK_QKV>(M, 3 * J, 2 * J);
+    const bool hoist = m->hoist_q && cond0 && NP == 2 && row0 == 0 && !chain && tq.bm == 64 && J % tq.bn == 0 && BT % 64 == 0 &&
+                       pick_tile<NP, TK_SQUARE>(M, D, 0).bm == kNarrowTile && pick_tile<NP, TK_SQUARE>(BT, J, 0).bm == kNarrowTile;
     if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
       WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
       // The layer's cached cross-attention K and V^T (14 MB at base, HBM-cold at every step: nothing touched
-      // them since the previous step) ride on this launch's prefetch waves, three launches ahead of their
-      // consumer.  With the in-epilogue prefetch the same idea cost the producer 3 us and won 1;
-      // from a wave of its own it costs the producer nothing.  Bounded by the segment's key count on the device.
+      // them since the previous step) can ride on this launch's prefetch waves (MSD_PF_KV=1; off: see pf_kv).
       if (kPfWave && m->prefetch && m->pf_kv && cond0 && NP == 2 && batch == 1 && m->n_cross == 1 && row0 == 0) {
         const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
         PrefetchTarget tk, tv;
@@ -1096,12 +1107,31 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         tv.dyn = m->d_nkeys_cross; tv.dyn_mode = 2;
         if (tv.lpr <= 64) { pf.add(tk); pf.add(tv); }
       }
-      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
+      if (hoist) {
+        if constexpr (NP == 2) {
+          GemmParams p1 = gp<NP>(y, D, w.self.wqkv, D, M, 3 * J, D);
+          p1.pf = pf; if (p1.pf.n > 1) p1.pf.n = 1;
+          p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_QKV + 1u;
+          set_xcd_grid(p1, KC_GEMM_QKV, M, 64);
+          GemmParams p2 = gp<NP>(m->yc, D, w.wq_cross[0], D, BT, J, D);
+          p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
+          set_xcd_grid(p2, KC_GEMM_CROSS_Q, BT, 64);
+          EpiStoreF32 ef;
+          ef.out = m->qpart; ef.ldc = J;
+          c.begin(KC_GEMM_QKV);
+          const hipError_t e = tq.bn == 96 ? launch_gemm_h16_dual<NP, 64, 96, 3, 0>(p1, eq, p2, ef, c.s)
+                                           : launch_gemm_h16_dual<NP, 64, 64, 3, 0>(p1, eq, p2, ef, c.s);
+          if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+          c.end(KC_GEMM_QKV);
+        }
+      } else {
+        gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
+      }
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
       const WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D)
-                                : (m->hoist_q && w.wq2.p[0] ? prefetch_of<NP>(m, w.wq2, J, D + J) : prefetch_of<NP>(m, w.wq_cross[0], J, D));
+                                : (hoist ? prefetch_of<NP>(m, w.w2, J, J) : prefetch_of<NP>(m, w.wq_cross[0], J, D));
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
     }
@@ -1113,30 +1143,21 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1): its input is
-    // LN(x1) = rstd(x1) (x1 (.) gamma) with x1 = x0 + ao . Wo, so
-    //   (x1 (.) gamma) . Wq = [x0 (.) gamma | ao] . [Wq ; Wo . diag(gamma) . Wq]
-    // depends on nothing the out-projection computes: both GEMMs run in ONE launch (gemm_h16_dual_kernel), the
-    // 1/rms moves onto the logits inside the attention kernel (AttnParams::q_ssq), and the launch boundary in
-    // front of the query projection (6.2 us of a 93 us layer in round 2) disappears.  x0 (.) gamma arrives as the
-    // planes `yc`, written by whichever epilogue produced x0 (input projection / previous layer's MLP output).
-    const bool hoist = m->hoist_q && cond0 && NP == 2 && row0 == 0 && pick_tile<NP, TK_SQUARE>(M, D, 0).bm == kNarrowTile &&
-                       pick_tile<NP, TK_SQUARE>(BT, J, 0).bm == kNarrowTile;
-    if (hoist) {
+    if (hoist) {   // out-projection + second half of the hoisted query projection in one launch (see above)
       if constexpr (NP == 2) {
         er.g_lo = nullptr; er.g_lo_stride = 0;   // the conditional rows' y = x1 (.) gamma_cross has no reader any more
         GemmParams p1 = gp<NP>(ao, J, w.self.wo, J, M, D, J);
         p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_ATTN_OUT + 1u;
         set_xcd_grid(p1, KC_GEMM_ATTN_OUT, M, kNarrowTile);
         p1.pf = prefetch_of<NP>(m, w.wo_cross[0], D, J);
-        GemmParams p2 = gp<NP>(m->yc, D, w.wq2, D + J, BT, J, D + J);
-        p2.A2[0] = ao.p[0]; p2.A2[1] = ao.p[NP - 1]; p2.lda2 = J; p2.k_split = D;
+        GemmParams p2 = gp<NP>(ao, J, w.w2, J, BT, J, J);
         p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
         set_xcd_grid(p2, KC_GEMM_CROSS_Q, BT, kNarrowTile);
-        EpiStoreH16<NP> es;
-        es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // rsc stays empty: stored un-normalised
+        EpiAddStoreH16<NP> es;
+        es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // stored un-normalised
+        es.addend = m->qpart; es.ld_add = J;
         c.begin(KC_GEMM_ATTN_OUT);
-        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4>(p1, er, p2, es, c.s);
+        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4, 0>(p1, er, p2, es, c.s);
         if (e != hipSuccess && c.err == hipSuccess) c.err = e;
         c.end(KC_GEMM_ATTN_OUT);
       }
@@ -1214,7 +1235,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     {
       const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
-      const WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+      WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+      if (hoist && !last_layer) pf_qkv.add(weights_target<NP>(m, m->dec[l + 1].wq_cross[0], J, D));   // first half of its hoisted q
       if constexpr (NP == 2) {
         if (splitk_fits(m, NP, M, D, F)) {
           gemm_splitk<NP>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, &pf_qkv);
@@ -1258,7 +1280,8 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
   if (m->hoist_q) { ei.y2[0] = m->yc.p[0]; ei.y2[1] = m->yc.p[NP - 1]; ei.g2 = m->dec[0].ln_cross; }
-  const WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
+  WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
+  if (m->hoist_q) pf.add(weights_target<NP>(m, m->dec[0].wq_cross[0], m->J, m->D));
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 
@@ -1314,7 +1337,9 @@ void set_func_attrs() {
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
-  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiStoreH16<2>>();
+  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>, 0>();
+  (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32, 0>();
+  (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32, 0>();
 }
 
 }  // namespace
@@ -1433,7 +1458,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
   TRY(palloc(m, &m->zp, (size_t)m->Bmax * T * m->ND));
-  if (m->hoist_q) TRY(palloc(m, &m->yc, (size_t)m->Bmax * T * D));
+  if (m->hoist_q) {
+    TRY(palloc(m, &m->yc, (size_t)m->Bmax * T * D));
+    TRY(dalloc(m, &m->qpart, (size_t)m->Bmax * T * J));
+  }
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
   m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
@@ -1583,8 +1611,8 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
     if (m->hoist_q) {
-      // q' = (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  [x0 (.) gamma | ao] . [Wq ; Wo . diag(gamma) . Wq]:
-      // the second block in float32 on the exact-fp32 MFMA, then both packed side by side along K
+      // q' = (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  (x0 (.) gamma) . Wq + ao . (Wo . diag(gamma) . Wq):
+      // the second matrix in float32 on the exact-fp32 MFMA, then packed like any other weight
       const std::string cp = lp + "/MultiHeadDotProductAttention_0";
       float *gwq = nullptr, *w2 = nullptr;
       HIP_TRY(m, hipMalloc(&gwq, (size_t)D * J * sizeof(float)));
@@ -1595,9 +1623,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       gp2.A = W(m, lp + "/self_attention/out/kernel"); gp2.B = gwq; gp2.lda = D; gp2.ldb = J; gp2.M = J; gp2.N = J; gp2.K = D;
       hipError_t e = launch_gemm_f32(gp2, EpiF32Store{w2, J}, s);
       if (e == hipSuccess) {
-        if ((rc = palloc(m, &w.wq2, (size_t)J * (D + J))) == MSD_OK &&
-            (rc = pack(m, s, W(m, cp + "/query/kernel"), D, J, w.wq2, 0, 0, D + J, 0)) == MSD_OK)
-          rc = pack(m, s, w2, J, J, w.wq2, 0, 0, D + J, D);
+        if ((rc = palloc(m, &w.w2, (size_t)J * J)) == MSD_OK) rc = pack(m, s, w2, J, J, w.w2, 0, 0);
       }
       const hipError_t es = hipStreamSynchronize(s);
       (void)hipFree(gwq); (void)hipFree(w2);
