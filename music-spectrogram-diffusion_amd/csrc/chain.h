@@ -22,7 +22,7 @@ namespace msd {
 #endif
 constexpr int kChainCP = MSD_CHAIN_CP;   // 16 = sc1: bypass the CU's L1, hit the XCD's L2
 constexpr int kChainSpinLimit = 4000000;
-constexpr int kBarStride = 64;        // one counter per XCD, 256 B apart
+constexpr int kBarStride = 64;        // one counter per XCD, 256 B apart; word 1 of a slot = the XCC_ID its blocks reported
 
 // Barrier among the `n` blocks of this XCD.  `cnt` is monotonic (never reset): the arrival index tells the
 // round.  Every wave first waits for its own stores to reach L2.  The spin is bounded: a lost block (e.g. fewer
@@ -34,7 +34,8 @@ __device__ __forceinline__ void xcd_barrier(unsigned* cnt, unsigned n, int* err)
     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (old / n + 1) * n;
     int spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    // wrap-safe compare (the counters are also zeroed at the start of every msd_* call: msd_api.hip reset_sync_words)
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       if (++spins > kChainSpinLimit) { atomicAdd(err, 1); break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -79,6 +80,16 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(MlpChainParams<NP> P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
   unsigned* bar = P.bar + xcd * kBarStride;
+  // The chain's correctness rests on an OBSERVED placement (block b runs on XCD b % 8): every block reports its
+  // XCC_ID to its slot's placement word; a second value in one slot raises *err (bit 16 up), which fails the
+  // msd_* call that launched the chain (msd_api.hip check_sync_words).
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xf) + 1u;
+    const unsigned seen = atomicCAS(bar + 1, 0u, xcc);
+    if (seen != 0u && seen != xcc) atomicAdd(P.err, 1 << 16);
+  }
   chain_gemm_phase<NP, 64, 128, 3>(P.g_in, P.e_in, xcd, slot, nslot, smem);
   xcd_barrier(bar, nslot, P.err);
   chain_gemm_phase<NP, 64, 32, 4>(P.g_out, P.e_out, xcd, slot, nslot, smem);

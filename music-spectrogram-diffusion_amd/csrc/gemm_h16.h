@@ -181,10 +181,6 @@ struct GemmParams {
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
   unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
-  // K-concatenated A operand (gemm_tile DA = 1): K-tiles from k_split on are read from A2 (row stride lda2) at
-  // column k - k_split -- the hoisted cross-attention query projection multiplies [x (.) gamma | attention output]
-  const h16_t* A2[2] = {nullptr, nullptr};
-  int lda2 = 0, k_split = 0;
   // split-K launches (gemm_h16_splitk_kernel): exchange workspace [tile][dest split][src split][BM][BN/SK] fp32,
   // one monotonic arrival counter and SK placement words per tile, an error word (bit 16+: placement, low: timeout)
   float* sk_part = nullptr;
@@ -247,10 +243,9 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // it multiplies K-tiles [ks K/SK, (ks+1) K/SK) and, after the exchange described at the kernel, runs the epilogue
 // on columns [n0 + ks BN/SK, +BN/SK) of the tile.
 constexpr int kSplitSpinLimit = 2000000;
-template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1, int DA = 0>
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem, int ks = 0,
                                           int tile_id = 0) {
-  static_assert(!(DA && SK > 1), "the K-concatenated A operand is not combined with split-K");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int BNE = BN / SK;                    // columns of the tile this block's epilogue owns
   constexpr int FM = WM / 16, FN = WN / 16;
@@ -277,14 +272,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     gb[pl] = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
   }
   const size_t a_step = (size_t)8 * p.lda, b_step = (size_t)8 * p.ldb;
-  // DA: second source of the A operand for K-tiles at k >= p.k_split (a block-uniform choice per K-tile)
-  const h16_t* ga2[NP];
-#pragma unroll
-  for (int pl = 0; pl < NP; ++pl)
-    ga2[pl] = DA ? p.A2[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda2 + csrc * 8 : ga[pl];
-  const size_t a_step2 = DA ? (size_t)8 * p.lda2 : a_step;
-#define MSD_A_SRC(PL, I, K0) \
-  ((DA && (K0) >= p.k_split) ? ga2[PL] + (I) * a_step2 + ((K0) - p.k_split) : ga[PL] + (I) * a_step + (K0))
+#define MSD_A_SRC(PL, I, K0) (ga[PL] + (I) * a_step + (K0))
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -650,13 +638,13 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_splitk_kernel(G
   gemm_tile<NP, BM, BN, NS, Epi, 0, PF, SK>(p, epi, bm, bn, smem, ks, bm * nbn + bn);
 }
 
-// Two independent GEMMs of one tile shape in ONE launch (no data flows between them): blocks [0, n2) run problem 2
-// (optionally with a K-concatenated A operand, DA2), the rest problem 1.  Used by the HOISTED cross-attention query
+// Two independent GEMMs of one tile shape in ONE launch (no data flows between them): blocks [0, n2) run problem 2,
+// the rest problem 1.  Used by the HOISTED cross-attention query
 // projection (msd_api.hip decoder_layers): its first half rides on the QKV launch's idle CUs, its second half on the
 // launch of the self-attention output projection -- a launch boundary less per layer.  Each problem keeps its own
 // XCD-aware tile map (n2 is a multiple of 8, so a block's XCD is the same in the launch-wide and in the
 // problem-local numbering).
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone, int DA2 = 0>
+template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone>
 __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (kPfWave && PF != kPfNone) {
@@ -687,7 +675,7 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(Gem
     gemm_tile<NP, BM, BN, NS, Epi1, 0, kPfNone>(p1, e1, bm, bn, smem);
     return;
   }
-  gemm_tile<NP, BM, BN, NS, Epi2, 0, PF, 1, DA2>(p2, e2, bm, bn, smem);
+  gemm_tile<NP, BM, BN, NS, Epi2, 0, PF>(p2, e2, bm, bn, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -1324,13 +1312,13 @@ constexpr int gemm_h16_dual_smem() {
   constexpr int a = gemm_h16_dma_smem<NP, BM, BN, NS, Epi1>(), b = gemm_h16_dma_smem<NP, BM, BN, NS, Epi2>();
   return a > b ? a : b;
 }
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int DA2>
+template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
 inline hipError_t gemm_h16_dual_prepare() {
   constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
   if (smem < 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0, DA2>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1, DA2>),
+  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return e != hipSuccess ? e : r;
 }
@@ -1338,20 +1326,19 @@ inline int gemm_grid_blocks(const GemmParams& p, int BM, int BN) {
   const int rx = p.xcd_rows, cx = 8 / rx;
   return 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
 }
-// p1 / e1: the first problem; p2 / e2: the second (DA2 = 1: K-concatenated A operand, p2.A2 / lda2 / k_split set).
-// The weight prefetch target (at most one) is taken from p1.pf.
-template <int NP, int BM, int BN, int NS, int DA2, class Epi1, class Epi2>
+// p1 / e1: the first problem; p2 / e2: the second.  The weight prefetch target (at most one) is taken from p1.pf.
+template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
 inline hipError_t launch_gemm_h16_dual(const GemmParams& p1, const Epi1& e1, GemmParams p2, const Epi2& e2, hipStream_t stream) {
   constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
-  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM, BN, NS, Epi1, Epi2, DA2>();
+  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM, BN, NS, Epi1, Epi2>();
   if (attr != hipSuccess) return attr;
   const int n1 = gemm_grid_blocks(p1, BM, BN), n2 = gemm_grid_blocks(p2, BM, BN);
   p2.pf = p1.pf;
   p2.pf_nblk = n2;
   if (NP == 2 && prefetch_kind(p1.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1, DA2>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
   else
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0, DA2>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
   return hipGetLastError();
 }
 

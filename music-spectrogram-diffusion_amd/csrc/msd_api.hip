@@ -170,9 +170,13 @@ struct msd_model {
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
-  // Hoisted cross-attention query projection (decoder_layers; MSD_HOIST_Q=0: off): needs the folded norms, the
-  // two-plane mode, one cross-attention module and D % 128 == 0
-  bool hoist_q = true;
+  // Hoisted cross-attention query projection (decoder_layers).  OFF by default: parity-green (tests/test_gpu_model.py,
+  // hoisted vs plain order 3e-7) and it removes one launch per layer, but measured 0 .. +1 % SLOWER per step on the
+  // MI355X in both forms (profiles/r03f_env_ab.log: K-concatenated, one dual launch; profiles/r03j_hoist_ab.log: two
+  // stages) -- the dual out-projection launch grows by what the query projection's own launch took, because its 576
+  // blocks no longer fit the 512 resident slots.  MSD_HOIST_Q=1 turns it on.  Needs the folded norms, the two-plane
+  // mode, one cross-attention module and D % 128 == 0.
+  bool hoist_q = false;
   Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
   float* qpart = nullptr;      // (x0 (.) gamma_cross) . Wq of the layer, fp32 [Bmax * T, J]: first half of the hoisted projection
   // Query-side single-plane attention of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q, 2 = P).
@@ -285,8 +289,8 @@ int check_sync_words(msd_model* m, const char* what) {   // call after the strea
                 "spread over several XCDs; the result of this call is invalid (MSD_SPLITK=0 selects the plain kernel)",
                 what, bad[0] & 0xffff, bad[0] >> 16);
   if (bad[1])
-    return fail(m, MSD_ERR_HIP, "%s: an XCD-resident chain kernel timed out at a barrier (%d times); the result of this "
-                "call is invalid (MSD_CHAIN=0)", what, bad[1]);
+    return fail(m, MSD_ERR_HIP, "%s: an XCD-resident chain kernel reported %d barrier timeouts and %d blocks that were not on "
+                "the XCD of their slot; the result of this call is invalid (MSD_CHAIN=0)", what, bad[1] & 0xffff, bad[1] >> 16);
   return MSD_OK;
 }
 
@@ -1119,8 +1123,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
           EpiStoreF32 ef;
           ef.out = m->qpart; ef.ldc = J;
           c.begin(KC_GEMM_QKV);
-          const hipError_t e = tq.bn == 96 ? launch_gemm_h16_dual<NP, 64, 96, 3, 0>(p1, eq, p2, ef, c.s)
-                                           : launch_gemm_h16_dual<NP, 64, 64, 3, 0>(p1, eq, p2, ef, c.s);
+          const hipError_t e = tq.bn == 96 ? launch_gemm_h16_dual<NP, 64, 96, 3>(p1, eq, p2, ef, c.s)
+                                           : launch_gemm_h16_dual<NP, 64, 64, 3>(p1, eq, p2, ef, c.s);
           if (e != hipSuccess && c.err == hipSuccess) c.err = e;
           c.end(KC_GEMM_QKV);
         }
@@ -1157,7 +1161,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // stored un-normalised
         es.addend = m->qpart; es.ld_add = J;
         c.begin(KC_GEMM_ATTN_OUT);
-        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4, 0>(p1, er, p2, es, c.s);
+        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4>(p1, er, p2, es, c.s);
         if (e != hipSuccess && c.err == hipSuccess) c.err = e;
         c.end(KC_GEMM_ATTN_OUT);
       }
@@ -1337,9 +1341,9 @@ void set_func_attrs() {
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
-  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>, 0>();
-  (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32, 0>();
-  (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32, 0>();
+  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>>();
+  (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32>();
+  (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32>();
 }
 
 }  // namespace

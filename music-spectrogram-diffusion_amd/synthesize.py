@@ -28,7 +28,12 @@ def main(argv=None) -> int:
   ap.add_argument('--cfg-weight', type=float, default=5.0)
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--rng', choices=['philox', 'jax'], default='philox')
-  ap.add_argument('--precision', choices=['bf16x3', 'bf16'], default='bf16x3')
+  ap.add_argument('--precision', choices=['f16x3', 'f16', 'bf16x3', 'bf16'], default='f16x3',
+                  help="'f16x3' (default): hi + lo IEEE-half operand planes, float32-class; 'bf16x3': bfloat16 planes "
+                       "(float32's exponent range, twice the rounding error); 'f16' / 'bf16': one plane, not parity-grade")
+  ap.add_argument('--range-fallback', action='store_true',
+                  help="switch to 'bf16x3' and repeat the segment if an activation leaves the half-plane range "
+                       "(native.RangeError) instead of failing")
   ap.add_argument('--out', default=None, help='.npy file for the mel frames [frames, 128]')
   ap.add_argument('--on-too-long', choices=['error', 'truncate'], default='error')
   ap.add_argument('--dry-run', action='store_true')
@@ -51,7 +56,7 @@ def main(argv=None) -> int:
            float(np.mean(n_tok)), max(n_tok), t_tok), file=sys.stderr)
   if args.dry_run:
     return 0
-  model = msd_amd.InferenceModel(args.checkpoint, spec, precision=args.precision)
+  model = msd_amd.InferenceModel(args.checkpoint, spec, precision=args.precision, range_fallback=args.range_fallback)
   mel, timing = model.predict_sequence(segments, seed=args.seed, rng=args.rng, return_timing=True)
   frames = int(np.ceil(ns.total_time * cfg.frame_rate))
   mel = mel[0, :max(frames, 1)]
