@@ -98,12 +98,15 @@ def assert_fp32_class(got, ref64, ref32, what=''):
   # decoder passes agree to 4e-6 relative (round 2: a code-generation difference in the attention kernel,
   # DESIGN 11) gave 0.0001 and 0.0020 on the tiny golden, against the float32 oracle's 0.0002.
   assert out_dev <= 2 * out_f32 + 3e-3, 'too many outliers'
-  # A third, sharp criterion that does not depend on WHICH elements flip at a clip: the rms over
-  # the common bulk -- elements the float32 oracle itself gets right to 1e-4 and the device to 1e-2 (flips are counted
-  # above) -- must stay within 3x the float32 oracle's rms over the same elements.  The median is blind to an error of
-  # 1e-4 on a third of the elements; this is not.
-  bulk = (e_f32 <= 1e-4) & (e_dev <= 1e-2)
-  if bulk.sum() >= 0.5 * bulk.size:
-    r_dev, r_f32 = float(np.sqrt(np.mean(e_dev[bulk] ** 2))), float(np.sqrt(np.mean(e_f32[bulk] ** 2)))
-    print('%s bulk rms (%.1f %% of the elements): device %.2e / f32-oracle %.2e' % (what, 100.0 * bulk.mean(), r_dev, r_f32))
-    assert r_dev <= 3 * r_f32 + 2e-6, 'bulk rms is not fp32-class'
+  # A third criterion, on the error DISTRIBUTION below the outlier threshold (the two above
+  # are nearly blind to a kernel that is moderately wrong everywhere).  A short chain turns one rounding into a
+  # spread of errors between 1e-6 and 1e-2 whatever the arithmetic, on different elements for every evaluation -- so an
+  # rms over "the elements the float32 oracle gets right" cannot work (measured on the MI355X: the device's rms over
+  # those is 3 - 8x the float32 oracle's, simply because its amplified elements are other ones).  What two float32-
+  # class evaluations do share is HOW MANY elements end up beyond a given error: on tiny_context the float32 oracle,
+  # the half-plane emulation and the bfloat16-plane emulation have 5.4 / 5.5 / 6.5 % of their elements beyond 1e-3 and
+  # 27.1 / 27.5 / 30.5 % beyond 1e-4, a single half plane ('f16') 33 % and 35 %.
+  for tau, factor, slack in ((1e-3, 1.5, 0.02), (1e-4, 1.3, 0.03)):
+    f_dev, f_f32 = float((e_dev > tau).mean()), float((e_f32 > tau).mean())
+    print('%s elements beyond %.0e: device %.4f / f32-oracle %.4f' % (what, tau, f_dev, f_f32))
+    assert f_dev <= factor * f_f32 + slack, 'too many elements beyond %.0e for float32-class arithmetic' % tau
