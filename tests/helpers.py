@@ -106,7 +106,9 @@ def assert_fp32_class(got, ref64, ref32, what=''):
   # class evaluations do share is HOW MANY elements end up beyond a given error: on tiny_context the float32 oracle,
   # the half-plane emulation and the bfloat16-plane emulation have 5.4 / 5.5 / 6.5 % of their elements beyond 1e-3 and
   # 27.1 / 27.5 / 30.5 % beyond 1e-4, a single half plane ('f16') 33 % and 35 %.
-  for tau, factor, slack in ((1e-3, 1.5, 0.02), (1e-4, 1.3, 0.03)):
+  # MI355X, 46 short-chain cases (profiles/r03l_tests.log): the device is within +-0.02 of the float32 oracle's fraction at
+  # both thresholds (worst ratio 1.07)
+  for tau, factor, slack in ((1e-3, 1.25, 0.01), (1e-4, 1.15, 0.01)):
     f_dev, f_f32 = float((e_dev > tau).mean()), float((e_f32 > tau).mean())
     print('%s elements beyond %.0e: device %.4f / f32-oracle %.4f' % (what, tau, f_dev, f_f32))
     assert f_dev <= factor * f_f32 + slack, 'too many elements beyond %.0e for float32-class arithmetic' % tau
