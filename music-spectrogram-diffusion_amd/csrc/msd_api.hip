@@ -20,7 +20,6 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_h16.h"
-#include "gemm_h16_k32.h"
 #include "gemm_f32.h"
 
 using namespace msd;
@@ -161,7 +160,6 @@ struct msd_model {
   bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
   // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
   bool chain_mlp = false;
-  bool big_k32 = true;         // batched path: 128-row tiles on K-tiles of 32 with a 4-deep ring (gemm_h16_k32.h; MSD_BIG_K32=0: the 2-deep K = 64 tiles)
   bool prefetch = true;        // producers warm the next GEMM's weights in L2 (MSD_PREFETCH=0: off)
   // prefetch-wave builds: the QKV launch also warms the layer's cached cross-attention K / V^T.  OFF: measured +2.5 %
   // step time on the MI355X (profiles/r03g_env_ab.log: 1099-1105 vs 1073-1075 ms per segment): cross-attention wins
@@ -441,20 +439,6 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.end(kc);
 }
 
-// the same launch on the batched path's K = 32 tiles (gemm_h16_k32.h)
-template <int NP, int BM, int BN, int NS, class Epi>
-void gemm_t_k32(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
-                const Epi& epi, const WeightPrefetch* pf = nullptr) {
-  c.begin(kc);
-  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
-  if (pf) p.pf = *pf;
-  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  set_xcd_grid(p, kc, M, BM);
-  hipError_t e = launch_gemm_h16_k32<NP, BM, BN, NS, Epi>(p, epi, c.s);
-  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
-  c.end(kc);
-}
-
 constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
 
 // rounds of blocks over the 256 CUs x rows of operand per K-tile: the GEMMs sit on the per-CU ingest
@@ -507,11 +491,12 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
           const Epi& epi, int align = 0, const WeightPrefetch* pf = nullptr) {
   const TileShape t = pick_tile<NP, TK>(M, N, align);
 #define MSD_GO(BM_, BN_, NS_) return gemm_t<NP, BM_, BN_, NS_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf)
-#define MSD_GO_BIG(BM_, BN_)                                                                                   \
-  {                                                                                                            \
-    if (c.m->big_k32 && K % kK32 == 0) return gemm_t_k32<NP, BM_, BN_, 4, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf); \
-    MSD_GO(BM_, BN_, 2);                                                                                       \
-  }
+// Batched songs: 128-row tiles, 2-deep ring of K = 64 tiles.  A 4-deep ring of K = 32 tiles (64-byte rows, its own
+// swizzle and a plain one-barrier-per-tile loop: tools/ubench/gemm_h16_k32.h) was built in round 3, is parity-green on
+// the batched test and measured 10 % SLOWER end to end at 8 and 16 songs (profiles/r03m_k32_ab.log: 465 vs 516 and
+// 498 vs 550 mel-frames/s; gated MLP input 1.34 vs 1.13 ms per step): twice the barriers per K and one wave per SIMD
+// at 340 registers cost more than the deeper ring hides.  Not in the product build.
+#define MSD_GO_BIG(BM_, BN_) MSD_GO(BM_, BN_, 2);
   if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
       if (t.bm == 128) MSD_GO_BIG(128, 96)
@@ -1363,11 +1348,6 @@ void set_func_attrs() {
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
-  (void)gemm_h16_k32_prepare<2, 128, 96, 4, EpiQKV<2>>();
-  (void)gemm_h16_k32_prepare<2, 128, 128, 4, EpiGeglu<2>>();
-  (void)gemm_h16_k32_prepare<2, 128, 96, 4, EpiResidual>();
-  (void)gemm_h16_k32_prepare<2, 128, 96, 4, EpiResidualNorm<2>>();
-  (void)gemm_h16_k32_prepare<2, 128, 96, 4, EpiStoreH16<2>>();
   (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>>();
   (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32>();
   (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32>();
@@ -1381,7 +1361,7 @@ void set_func_attrs() {
 extern "C" {
 
 const char* msd_version(void) {
-  static const std::string v = std::string("msd_amd 0.3.0 (gfx950, abi 2, ") + kPlaneName + ")";
+  static const std::string v = std::string("msd_amd 0.4.0 (gfx950, abi 3, ") + kPlaneName + ")";
   return v.c_str();
 }
 
@@ -1441,7 +1421,6 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
   if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
   if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
-  if (const char* v = getenv("MSD_BIG_K32")) m->big_k32 = atoi(v) != 0;
   if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
   m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;

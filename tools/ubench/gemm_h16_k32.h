@@ -1,4 +1,9 @@
-// The batched path's GEMM main loop (M = passes x songs x T >= 2048 rows): 128-row tiles on K-tiles of 32.
+// EXPERIMENT RECORD, not part of the product build (round 3).  Parity-green when it was wired
+// into csrc/msd_api.hip (tests/test_gpu_model.py::test_batched_songs_use_big_tiles_and_match_oracle, profiles/
+// r03m_batched_test.log) and 10 % SLOWER than the 2-deep K = 64 tiles at 8 and 16 songs per GPU (profiles/r03m_k32_ab.log).
+// To re-run: include it next to csrc/gemm_h16.h, route the 128-row tiles of msd_api.hip's gemm<> to launch_gemm_h16_k32.
+//
+// A batched-path GEMM main loop (M = passes x songs x T >= 2048 rows): 128-row tiles on K-tiles of 32.
 //
 // Why another loop.  With several songs per handle every CU owns several 128 x 128 (128 x 96) tiles, and the
 // ablation of the 128-row tiles of gemm_h16.h (profiles/r02_gemm_ablation.log) showed the loop bound by
@@ -18,7 +23,7 @@
 //
 // Epilogues, tile map and launch conventions are those of gemm_h16.h (the weight prefetch: see the end of gemm_tile_k32).
 #pragma once
-#include "gemm_h16.h"
+#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 
 namespace msd {
 
