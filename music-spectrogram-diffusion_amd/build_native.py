@@ -61,8 +61,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
       continue
     with tempfile.TemporaryDirectory(prefix='msd_build_') as tmp:
       out = os.path.join(tmp, os.path.basename(lib))
+      # the output is named RELATIVE to the scratch cwd: an absolute path in a randomly named directory ends up
+      # inside the library and would give every build of the same sources another sha256 (the profiles are stamped
+      # with the hash of the library they ran on; built this way it is reproducible: same sources + compiler -> same hash)
       cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-save-temps',
-             '-fno-gpu-rdc', '-Wno-unused-result', '-I', CSRC] + defs + ['-o', out] + [os.path.join(CSRC, s) for s in SOURCES]
+             '-fno-gpu-rdc', '-Wno-unused-result', '-I', CSRC] + defs + ['-o', os.path.basename(lib)] + [os.path.join(CSRC, s) for s in SOURCES]
       if verbose:
         print('[build_native]', ' '.join(cmd), flush=True)
       subprocess.run(cmd, check=True, cwd=tmp)
