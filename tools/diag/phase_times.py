@@ -13,7 +13,7 @@ s_memtime (core clock) gives the deltas inside one block, s_memrealtime (100 MHz
 blocks with each other and calibrates the core clock.  The product library has none of this (the patch is not
 applied to the tree; the default build's hash is unchanged).
 
-usage (GPU box):  MSD_AMD_LIB=tools/ab/libs/libmsd_amd_ts.so python tools/diag/phase_times.py"""
+usage (GPU box):  [BATCH=8] MSD_AMD_LIB=tools/ab/libs/libmsd_amd_ts.so python tools/diag/phase_times.py"""
 import ctypes
 import os
 import sys
@@ -26,8 +26,9 @@ import msd_amd
 from msd_amd import native
 from tests import helpers
 
-CLASSES = ['64x128 (MLP-in GEGLU, last layer)', '64x96 (QKV, last layer)', '64x64 (last such launch of the step)',
-           '32x32 (narrow: last such launch of the step)']
+CLASSES = ['BN = 128 (gated MLP-in, last layer: 64 x 128 at one song, 128 x 128 batched)',
+           'BN = 96 (one song: QKV, last layer, 64 x 96; batched: the last 128 x 96 launch of the step)',
+           '64 x 64 (last such launch of the step)', 'narrow tiles (the last such launch of the step)']
 
 
 def pct(v):
@@ -35,11 +36,12 @@ def pct(v):
 
 
 def main():
-  steps = int(os.environ.get('STEPS', '16'))
+  steps, nb = int(os.environ.get('STEPS', '16')), int(os.environ.get('BATCH', '1'))
   spec = msd_amd.config.preset('base_with_context', num_steps=steps)
-  model = msd_amd.InferenceModel('synthetic:0', spec)
-  batch = helpers.make_batch(spec)
-  init_z, noise = helpers.make_noise(spec)
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb)
+  batch = helpers.make_batch(spec, batch=nb)
+  init_z, noise = helpers.make_noise(spec, batch=nb)
+  print('base_with_context, %d song(s) per handle, %d steps' % (nb, steps))
   for _ in range(2):   # the second run is the graph replay, weights staged, clocks up
     model.predict(batch, init_z=init_z, noise=noise)
   torch.cuda.synchronize()
