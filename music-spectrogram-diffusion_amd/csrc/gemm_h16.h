@@ -25,6 +25,7 @@
 // column slice are consecutive on ONE XCD, so a weight slice is fetched from HBM
 // once into that XCD's L2.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace msd {
@@ -765,13 +766,52 @@ __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, 
 
 typedef const __attribute__((address_space(3))) float* lds_cf32;   // explicit LDS pointer: ds_read, not flat_load
 
-// The bias row of a tile (index 0 = column n0): prefetched into LDS (aux) or read from global memory.
+// The bias row of a tile (index 0 = column n0), in the aux LDS region (rowscale_prefetch put it there).  Always LDS:
+// with a second, global-memory form behind a run-time flag every element of the epilogue loops went through two
+// scalar branches and -- at the join of the two forms -- an s_waitcnt vmcnt(0), i.e. the second pass of a thread
+// over its items waited for the STORES of the first (phase stamps, profiles/r03p_phase_times_b1.txt: 2.5 us between
+// slab and stores on the gated-MLP-in tile, 1.9 us on the QKV tile).
+typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
 struct BiasRow {
-  const float* g = nullptr;
   lds_cf32 l = nullptr;
-  bool in_lds = false, present = false;
-  __device__ __forceinline__ float at(int i) const { return in_lds ? l[i] : g[i]; }
+  bool present = false;
+  __device__ __forceinline__ float at(int i) const { return l[i]; }
+  // entries i .. i + 7 (i a multiple of 4): two ds_read_b128
+  __device__ __forceinline__ void at8(int i, float (&b)[8]) const {
+    const f32x4 b0 = reinterpret_cast<lds_cf32x4>(l + i)[0], b1 = reinterpret_cast<lds_cf32x4>(l + i)[1];
+    b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3];
+    b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
+  }
 };
+
+// The three forms of an epilogue's element loop -- 0: plain, 1: times rstd[m], 2: times rstd[m] plus bias[n] --
+// as compile-time variants chosen ONCE per launch, so the loops themselves are branch-free.
+template <class F>
+__device__ __forceinline__ void rowscale_variants(bool folded, bool has_bias, F&& f) {
+  if (!folded) f(std::integral_constant<int, 0>{});
+  else if (!has_bias) f(std::integral_constant<int, 1>{});
+  else f(std::integral_constant<int, 2>{});
+}
+
+// v = v * rs + bias[i .. i + 7] in form MODE (see rowscale_variants)
+template <int MODE>
+__device__ __forceinline__ void rowscale8(float (&v)[8], float rs, const BiasRow& bias, int i) {
+  if constexpr (MODE == 2) {
+    float b[8];
+    bias.at8(i, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * rs + b[e];
+  } else if constexpr (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * rs + 0.f;
+  }
+}
+
+// element loops of the epilogues: item = tid, tid + 256, ... < ITEMS with a compile-time trip count (fully unrolled:
+// the LDS reads of all passes are issued up front)
+#define MSD_EPI_ITEMS(ITEMS, item)                                             \
+  _Pragma("unroll") for (int it_ = 0; it_ < ((ITEMS) + 255) / 256; ++it_)      \
+    if (const int item = tid + it_ * 256; ((ITEMS) % 256 == 0) || item < (ITEMS))
 
 // rstd of the BM rows of this tile into LDS (rs[0..BM)); block-wide, ends with a barrier.  All 256
 // threads take part (256 / BM per row, then a shuffle tree): the serial 24-term sum by BM threads
@@ -805,9 +845,9 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
   }
   BiasRow b;
   if (r.bias) {
+    if (!aux) __builtin_trap();   // the bias row lives in the aux LDS region (every product kernel has one)
     b.present = true;
-    if (aux) { b.in_lds = true; b.l = (lds_cf32)(aux + BM * kAuxMaxTiles * 4); }
-    else b.g = r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0;
+    b.l = (lds_cf32)(aux + BM * kAuxMaxTiles * 4);
   }
   return b;
 }
@@ -834,16 +874,15 @@ struct EpiStoreH16 {
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     RangeCheck rc;
-    for (int item = tid; item < BM * BN / 8; item += 256) {
-      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
-      float v[8];
-      tile_row8<LD>(s0, m, n, v);
-      if (rsc.ssq) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
+    rowscale_variants(rsc.ssq != nullptr, bias.present, [&](auto mode) {
+      MSD_EPI_ITEMS(BM * BN / 8, item) {
+        const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+        float v[8];
+        tile_row8<LD>(s0, m, n, v);
+        rowscale8<decltype(mode)::value>(v, decltype(mode)::value ? rs[m] : 1.f, bias, n);
+        store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
       }
-      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
-    }
+    });
     rc.commit(sf.p, sf.tag);
   }
 };
@@ -921,28 +960,30 @@ struct EpiQKV {
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     RangeCheck rc;
     if (n0 < v_start) {
-      for (int item = tid; item < BM * BN / 8; item += 256) {
-        const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
-        float v[8];
-        tile_row8<LD>(s0, m, n, v);
-        if (rsc.ssq) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
+      rowscale_variants(rsc.ssq != nullptr, bias.present, [&](auto mode) {
+        MSD_EPI_ITEMS(BM * BN / 8, item) {
+          const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+          float v[8];
+          tile_row8<LD>(s0, m, n, v);
+          rowscale8<decltype(mode)::value>(v, decltype(mode)::value ? rs[m] : 1.f, bias, n);
+          store_h16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v, rc);
         }
-        store_h16x8<NP>(qk, (size_t)(m0 + m) * ld_qk + n0 + n, v, rc);
-      }
+      });
     } else {
       // transposed items: (column n, 8 consecutive rows = keys).  Keys o..o+7 of a
       // 16-group land on two runs of 4 consecutive permuted positions.
-      for (int item = tid; item < BM * BN / 8; item += 256) {
+      const bool folded = rsc.ssq != nullptr;
+      MSD_EPI_ITEMS(BM * BN / 8, item) {
         const int n = item / (BM / 8), mm = (item % (BM / 8)) * 8;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
-        if (rsc.ssq) {
+        if (folded) {
+          float r8[8];
+          tile_row8<1>(rs, 0, mm, r8);   // rs[mm .. mm + 7]
           const float bn = bias.present ? bias.at(n) : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[mm + e] + bn;
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * r8[e] + bn;
         }
         const int mg = m0 + mm, seg = mg / seg_len, key = mg % seg_len;
         h16_t* base[2];
@@ -1197,18 +1238,17 @@ struct EpiStoreF32 {
     float* rs = s0 + BM * LD;
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
-    for (int item = tid; item < BM * BN / 8; item += 256) {
-      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
-      float v[8];
-      tile_row8<LD>(s0, m, n, v);
-      if (rsc.ssq) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * rs[m] + (bias.present ? bias.at(n + e) : 0.f);
+    rowscale_variants(rsc.ssq != nullptr, bias.present, [&](auto mode) {
+      MSD_EPI_ITEMS(BM * BN / 8, item) {
+        const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+        float v[8];
+        tile_row8<LD>(s0, m, n, v);
+        rowscale8<decltype(mode)::value>(v, decltype(mode)::value ? rs[m] : 1.f, bias, n);
+        float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
+        po[0] = make_float4(v[0], v[1], v[2], v[3]);
+        po[1] = make_float4(v[4], v[5], v[6], v[7]);
       }
-      float4* po = reinterpret_cast<float4*>(out + (size_t)(m0 + m) * ldc + n0 + n);
-      po[0] = make_float4(v[0], v[1], v[2], v[3]);
-      po[1] = make_float4(v[4], v[5], v[6], v[7]);
-    }
+    });
   }
 };
 
@@ -1239,23 +1279,21 @@ struct EpiGeglu {
     BiasRow bias;
     if (rsc.ssq) bias = tile_rstd<BM>(rsc, rs, m0, n0, tid, aux, stats_done);
     RangeCheck rc;
-    for (int item = tid; item < BM * OUT_N / 8; item += 256) {
-      const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
-      const int pc = (j / 16) * 32 + (j % 16);
-      float a[8], b[8], v[8];
-      tile_row8<LD>(s0, m, pc, a);
-      tile_row8<LD>(s0, m, pc + 16, b);
-      if (rsc.ssq) {
+    rowscale_variants(rsc.ssq != nullptr, bias.present, [&](auto mode) {
+      MSD_EPI_ITEMS(BM * OUT_N / 8, item) {
+        const int m = item / (OUT_N / 8), j = (item % (OUT_N / 8)) * 8;  // 8 output cols j..j+7
+        const int pc = (j / 16) * 32 + (j % 16);
+        float a[8], b[8], v[8];
+        tile_row8<LD>(s0, m, pc, a);
+        tile_row8<LD>(s0, m, pc + 16, b);
+        const float r = decltype(mode)::value ? rs[m] : 1.f;
+        rowscale8<decltype(mode)::value>(a, r, bias, pc);
+        rowscale8<decltype(mode)::value>(b, r, bias, pc + 16);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a[e] = a[e] * rs[m] + (bias.present ? bias.at(pc + e) : 0.f);
-          b[e] = b[e] * rs[m] + (bias.present ? bias.at(pc + 16 + e) : 0.f);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
+        store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v, rc);
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(a[e]) * b[e];
-      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 / 2 + j, v, rc);
-    }
+    });
     rc.commit(sf.p, sf.tag);
   }
 };

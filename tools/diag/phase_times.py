@@ -5,9 +5,15 @@ with -DMSD_TIMESTAMPS=1 (tools/README.md: "phase timestamps"), then reads the pe
 each tile shape:
 
   entry      block starts (first instruction behind the accumulator clear)
-  landed     K-tile 0 is in LDS (prologue DMA issued + first counted wait + barrier)
+  issued     the prologue's LDS-DMA instructions (NS K-tiles + the epilogue's aux rows) are issued
+  landed     K-tile 0 is in LDS (first counted wait + barrier)
   loop end   main loop finished (all MFMAs issued, fragment reads done)
-  epi end    epilogue finished and its stores have left (s_waitcnt vmcnt(0))
+  slab       accumulators in the LDS slab, row statistics done, barrier
+  epi issued epilogue arithmetic done, its global stores issued
+  left       the stores have left (s_waitcnt vmcnt(0))
+
+and the same for the attention kernels (Q loads + ring DMAs issued, stage 0 landed, key loop end, partials in LDS,
+merged + stored) and the key-split merge kernel (entry, end).
 
 s_memtime (core clock) gives the deltas inside one block, s_memrealtime (100 MHz, one counter for the chip) aligns
 blocks with each other and calibrates the core clock.  The product library has none of this (the patch is not
@@ -26,9 +32,17 @@ import msd_amd
 from msd_amd import native
 from tests import helpers
 
-CLASSES = ['BN = 128 (gated MLP-in, last layer: 64 x 128 at one song, 128 x 128 batched)',
-           'BN = 96 (one song: QKV, last layer, 64 x 96; batched: the last 128 x 96 launch of the step)',
-           '64 x 64 (last such launch of the step)', 'narrow tiles (the last such launch of the step)']
+CLASSES = ['GEMM, BN = 128 (gated MLP-in, last layer: 64 x 128 at one song, 128 x 128 batched)',
+           'GEMM, BN = 96 (one song: QKV, last layer, 64 x 96; batched: the last 128 x 96 launch of the step)',
+           'GEMM, other 64-row tiles (one song: the MLP output projection, 64 x 32 over K = 2048)',
+           'GEMM, narrow tiles (the last such launch of the step)',
+           'attention, 32 query rows per block (one song: decoder self-attention, last layer)',
+           'attention, 64 query rows per block (cross-attention, last layer)',
+           'key-split merge (last layer)', None]
+GEMM_PHASES = ['entry -> prologue DMAs issued', 'issued -> K-tile 0 landed', 'landed -> main loop end',
+               'loop end -> slab + row statistics', 'slab -> epilogue stores issued', 'issued -> stores have left']
+ATT_PHASES = ['entry -> Q loads + ring DMAs issued', 'issued -> stage 0 landed', 'landed -> key loop end',
+              'loop end -> partials in LDS', 'partials -> merged + stores issued', 'issued -> stores have left']
 
 
 def pct(v):
@@ -48,34 +62,36 @@ def main():
   lib = native.load('f16')
   if not hasattr(lib, 'msd_debug_timestamps'):
     raise SystemExit('this library has no msd_debug_timestamps: build it with the patch and -DMSD_TIMESTAMPS=1')
-  ts = np.zeros((4, 1024, 8), np.uint64)
+  ts = np.zeros((8, 1024, 12), np.uint64)
   rc = lib.msd_debug_timestamps(ctypes.c_void_p(ts.ctypes.data))
   assert rc == 0, rc
   for c, name in enumerate(CLASSES):
-    grid = int(ts[c, 0, 5])
-    if grid == 0:
+    grid = int(ts[c, 0, 9])
+    if grid == 0 or name is None:
       continue
     n = min(grid, 1024)
     t = ts[c, :n].astype(np.int64)
-    core = t[:, :4] - t[:, :1]                           # core-clock ticks since this block's entry
-    real = (t[:, 7] - t[:, 6]).astype(np.float64) * 10.  # ns, 10 ns resolution
-    ghz = core[:, 3].sum() / real.sum()                  # ticks per ns
-    ph = np.diff(core, axis=1) / ghz / 1e3               # us: landed-entry, loop-landed, epi-loop
-    entry = (t[:, 6] - t[:, 6].min()) * 0.01             # us since the first block of the launch started
-    end = (t[:, 7] - t[:, 6].min()) * 0.01
-    print('\n%s: grid %d blocks, core clock %.3f GHz (s_memtime / s_memrealtime)' % (name, grid, ghz))
-    print('  launch span first entry -> last epilogue end : %7.2f us' % end.max())
-    print('  per block (us)                     p10     p50     p90')
-    print('  entry after first block        %s' % pct(entry))
-    print('  entry -> K-tile 0 landed       %s' % pct(ph[:, 0]))
-    print('  landed -> main loop end        %s' % pct(ph[:, 1]))
-    print('  loop end -> epilogue + stores  %s' % pct(ph[:, 2]))
-    print('  block lifetime                 %s' % pct(ph.sum(1)))
-    xcc = t[:, 4]
-    for x in sorted(set(xcc.tolist())):
-      m = xcc == x
-      print('  XCD %d: %3d blocks, entries %6.2f..%6.2f us, last end %6.2f us, median lifetime %6.2f us'
-            % (x, m.sum(), entry[m].min(), entry[m].max(), end[m].max(), np.median(ph[m].sum(1))))
+    t = t[t[:, 11] > 0]                                  # blocks that left early (no work) never stamp the end
+    if c == 6:                                           # merge: entry and end only
+      t[:, 1:6] = t[:, :1]
+    core = t[:, :7] - t[:, :1]                           # core-clock ticks since this block's entry
+    real = (t[:, 11] - t[:, 10]).astype(np.float64) * 10.  # ns, 10 ns resolution
+    ghz = core[:, 6].sum() / real.sum()                  # ticks per ns
+    ph = np.diff(core, axis=1) / ghz / 1e3               # us per phase
+    entry = (t[:, 10] - t[:, 10].min()) * 0.01           # us since the first block of the launch started
+    end = (t[:, 11] - t[:, 10].min()) * 0.01
+    print('\n%s: grid %d blocks (%d stamped), core clock %.3f GHz (s_memtime / s_memrealtime)' % (name, grid, len(t), ghz))
+    print('  launch span first entry -> last block end : %7.2f us' % end.max())
+    print('  per block (us)                            p10     p50     p90')
+    print('  entry after first block               %s' % pct(entry))
+    for k, label in enumerate(GEMM_PHASES if c < 4 else ATT_PHASES):
+      if c == 6 and k != 5:
+        continue
+      print('  %-37s %s' % (label if c != 6 else 'entry -> stores have left', pct(ph[:, k])))
+    print('  block lifetime                        %s' % pct(ph.sum(1)))
+    xcc = t[:, 8]
+    print('  per XCD (blocks, last end us): ' + '  '.join('%d: %d, %.2f' % (x, (xcc == x).sum(), end[xcc == x].max())
+                                                          for x in sorted(set(xcc.tolist()))))
 
 
 if __name__ == '__main__':
