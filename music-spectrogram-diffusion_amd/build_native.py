@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libmsd_amd.so')
 LIBS = {'f16': (LIB, []), 'bf16': (os.path.join(CSRC, 'libmsd_amd_bf16.so'), ['-DMSD_PLANE_BF16=1'])}
 SOURCES = ['msd_api.hip']
-HEADERS = ['common.h', 'chain.h', 'gemm_h16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
+HEADERS = ['common.h', 'chain.h', 'gemm_h16.h', 'gemm_h16_pair.h', 'gemm_h16_wide.h', 'gemm_h16_ls.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
            os.path.join('..', '..', 'include', 'msd_amd.h')]
 
 

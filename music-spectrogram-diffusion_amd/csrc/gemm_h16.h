@@ -180,6 +180,7 @@ struct GemmParams {
   int pf_nblk = 0;    // blocks that take part in the prefetch (0 = the whole grid); they are blockIdx.x < pf_nblk
   int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
+  int aux_half = 0;      // gemm_h16_pair.h: bytes of aux LDS per 64-row half of the tile (set by its launcher)
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
   unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
   // split-K launches (gemm_h16_splitk_kernel): exchange workspace [tile][dest split][src split][BM][BN/SK] fp32,
@@ -752,16 +753,20 @@ __device__ __forceinline__ void aux_dma_row(const void* g, char* dst, int bytes,
   __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)dst, 16, 0, 0);
 }
 
-// RowScale aux layout: [BM * tiles ssq partials | pad to BM * kAuxMaxTiles floats][bias row, 1 KiB]
+// RowScale aux layout: [BM * tiles ssq partials, rounded up to whole KiB (the DMA's granule)][bias row, 1 KiB].  The
+// bias row sits right behind the partials this launch has (run-time `tiles`), so a kernel that sizes its LDS at launch
+// time (gemm_h16_pair.h) pays for D / 32 tiles, not for kAuxMaxTiles; rowscale_aux_bytes() is the compile-time bound.
 template <int BM>
 constexpr int rowscale_aux_bytes() { return BM * kAuxMaxTiles * 4 + 1024; }
+template <int BM>
+__host__ __device__ __forceinline__ int rowscale_ssq_bytes(int tiles) { return (BM * tiles * 4 + 1023) & ~1023; }
 
 template <int BM, int BN, int CP = 0>
 __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, int m0, int n0, int wave, int lane) {
   if (!r.ssq) return;
   aux_dma_linear<CP>(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
   if (r.bias && wave == 3)
-    aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + BM * kAuxMaxTiles * 4, BN * 4, lane);
+    aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + rowscale_ssq_bytes<BM>(r.tiles), BN * 4, lane);
 }
 
 typedef const __attribute__((address_space(3))) float* lds_cf32;   // explicit LDS pointer: ds_read, not flat_load
@@ -847,7 +852,7 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
   if (r.bias) {
     if (!aux) __builtin_trap();   // the bias row lives in the aux LDS region (every product kernel has one)
     b.present = true;
-    b.l = (lds_cf32)(aux + BM * kAuxMaxTiles * 4);
+    b.l = (lds_cf32)(aux + rowscale_ssq_bytes<BM>(r.tiles));
   }
   return b;
 }

@@ -20,6 +20,9 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_h16.h"
+#include "gemm_h16_pair.h"
+#include "gemm_h16_wide.h"
+#include "gemm_h16_ls.h"
 #include "gemm_f32.h"
 
 using namespace msd;
@@ -166,6 +169,12 @@ struct msd_model {
   // 1 us, but the QKV launch loses 2.2 -- its compute waves' first s_barrier also waits for the prefetch wave, whose 36
   // touches take longer to retire than the first K-tile takes to land.  MSD_PF_KV=1 turns it on.
   bool pf_kv = false;
+  // batched path (128-row tiles): K-tiles of 32, two blocks resident per CU (gemm_h16_pair.h; MSD_BIG_PAIR=0/1)
+  bool big_pair = false;
+  // batched path, gated-MLP input: 256 x 128 tiles on eight waves (gemm_h16_wide.h; MSD_BIG_WIDE=0/1)
+  bool big_wide = false;
+  // batched path, gated-MLP input: 256 x 128 tiles, four multiplying + four loader waves (gemm_h16_ls.h; MSD_BIG_LS=0/1)
+  bool big_ls = false;
   int cus = 0;                 // compute units of the device (chain grid = one block per CU)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
@@ -439,6 +448,44 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.end(kc);
 }
 
+// the same launch on the batched path's co-resident K = 32 tiles (gemm_h16_pair.h)
+template <int NP, int BM, int BN, class Epi>
+void gemm_t_pair(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(p, kc, M, BM);
+  hipError_t e = launch_gemm_h16_pair<NP, BM, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+// ... and on the 256 x 128 eight-wave tiles (gemm_h16_wide.h)
+template <int NP, int BN, class Epi>
+void gemm_t_wide(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(p, kc, M, 256);
+  hipError_t e = launch_gemm_h16_wide<NP, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+// ... and on the 256 x 128 tiles with loader waves (gemm_h16_ls.h)
+template <int NP, int BN, class Epi>
+void gemm_t_ls(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi,
+               const WeightPrefetch* pf) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(p, kc, M, 256);
+  hipError_t e = launch_gemm_h16_ls<NP, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
 constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
 
 // rounds of blocks over the 256 CUs x rows of operand per K-tile: the GEMMs sit on the per-CU ingest
@@ -496,7 +543,11 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 // the batched test and measured 10 % SLOWER end to end at 8 and 16 songs (profiles/r03m_k32_ab.log: 465 vs 516 and
 // 498 vs 550 mel-frames/s; gated MLP input 1.34 vs 1.13 ms per step): twice the barriers per K and one wave per SIMD
 // at 340 registers cost more than the deeper ring hides.  Not in the product build.
-#define MSD_GO_BIG(BM_, BN_) MSD_GO(BM_, BN_, 2);
+#define MSD_GO_BIG(BM_, BN_)                                                                                          \
+  {                                                                                                                   \
+    if (c.m->big_pair && K % kPairBK == 0) return gemm_t_pair<NP, BM_, BN_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi); \
+    MSD_GO(BM_, BN_, 2);                                                                                              \
+  }
   if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
       if (t.bm == 128) MSD_GO_BIG(128, 96)
@@ -505,6 +556,10 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     MSD_GO(64, 64, wide_ns(NP));
   } else if constexpr (TK == TK_MLP_IN) {
     if constexpr (NP == 2) {
+      if (t.bm == 128 && c.m->big_ls && gemm_h16_ls_fits<128>(M, N, K))
+        return gemm_t_ls<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf);
+      if (t.bm == 128 && c.m->big_wide && gemm_h16_wide_fits<128>(M, N, K))
+        return gemm_t_wide<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
       if (t.bm == 128) MSD_GO_BIG(128, 128)
       if (t.bn == 128) MSD_GO(64, 128, 3);
     }
@@ -1348,6 +1403,13 @@ void set_func_attrs() {
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
+  (void)gemm_h16_wide_prepare<2, 128, EpiGeglu<2>>();
+  (void)gemm_h16_ls_prepare<2, 128, EpiGeglu<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiQKV<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 128, EpiGeglu<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiResidual>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiResidualNorm<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiStoreH16<2>>();
   (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>>();
   (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32>();
   (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32>();
@@ -1423,6 +1485,9 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
   if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
   if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_PAIR")) m->big_pair = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_WIDE")) m->big_wide = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_LS")) m->big_ls = atoi(v) != 0;
   m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;
   if (cfg->attn_query_planes == 2) m->att_qp_self = m->att_qp_cross = 0;
   else if (cfg->attn_query_planes == 1 && m->NP == 2) m->att_qp_self = m->att_qp_cross = 3;

@@ -259,11 +259,17 @@ def test_empty_inputs_give_unconditional_result(tiny_ctx):
   helpers.assert_fp32_class(got, ref64, ref32, 'empty')
 
 
-def test_batched_songs_use_big_tiles_and_match_oracle():
+@pytest.mark.parametrize('switch', [None, 'MSD_BIG_PAIR', 'MSD_BIG_WIDE', 'MSD_BIG_LS'])
+def test_batched_songs_use_big_tiles_and_match_oracle(switch, monkeypatch):
   """16 songs per handle: M = 2*16*64 = 2048 rows -> the 128-row GEMM tiles of the batched
   path (msd_api.hip big_m_threshold).  emb 192 / 3 heads / mlp 256 make every N a multiple of the
-  96/128-column tiles so all big instantiations run; checked per song against the oracle."""
+  96/128-column tiles so all big instantiations run; checked per song against the oracle.
+  `switch`: the batched path's alternative tile kernels, off by default (built, parity-green, not
+  faster) -- K = 32 tiles with two blocks per CU (gemm_h16_pair.h, all five 128-row launches), the 256 x 128
+  eight-wave tile and the 256 x 128 tile with loader waves (gemm_h16_wide.h / gemm_h16_ls.h, gated-MLP input)."""
   import dataclasses
+  if switch:
+    monkeypatch.setenv(switch, '1')   # read by msd_create
   base = msd_amd.config.preset('tiny_context', num_steps=4)
   spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, emb_dim=192, num_heads=3))
   params = msd_amd.synthetic.init_params(spec, 5, norm_scale_jitter=0.1)

@@ -38,9 +38,12 @@ CLASSES = ['GEMM, BN = 128 (gated MLP-in, last layer: 64 x 128 at one song, 128 
            'GEMM, narrow tiles (the last such launch of the step)',
            'attention, 32 query rows per block (one song: decoder self-attention, last layer)',
            'attention, 64 query rows per block (cross-attention, last layer)',
-           'key-split merge (last layer)', None]
+           'key-split merge (last layer)',
+           'GEMM, 256 x 128 tile with loader waves (gemm_h16_ls.h, MSD_BIG_LS=1; consumer wave 0)']
 GEMM_PHASES = ['entry -> prologue DMAs issued', 'issued -> K-tile 0 landed', 'landed -> main loop end',
                'loop end -> slab + row statistics', 'slab -> epilogue stores issued', 'issued -> stores have left']
+LS_PHASES = ['entry -> tile 0 visible (first barrier)', 'first barrier -> main loop end', 'loop end -> aux rows landed',
+             'aux -> first 64-row pass done', 'first pass -> fourth pass done', 'issued -> stores have left']
 ATT_PHASES = ['entry -> Q loads + ring DMAs issued', 'issued -> stage 0 landed', 'landed -> key loop end',
               'loop end -> partials in LDS', 'partials -> merged + stores issued', 'issued -> stores have left']
 
@@ -74,6 +77,8 @@ def main():
     t = t[t[:, 11] > 0]                                  # blocks that left early (no work) never stamp the end
     if c == 6:                                           # merge: entry and end only
       t[:, 1:6] = t[:, :1]
+    if c == 7:                                           # loader-wave kernel: fields 0 1 2 3 4 5 6, [7] = loader's "prologue issued"
+      print('\n  (loader wave 4: entry -> 36 prologue DMAs issued, us p10/p50/p90: %s)' % pct((t[:, 7] - t[:, 0]) / 2.0e3))
     core = t[:, :7] - t[:, :1]                           # core-clock ticks since this block's entry
     real = (t[:, 11] - t[:, 10]).astype(np.float64) * 10.  # ns, 10 ns resolution
     ghz = core[:, 6].sum() / real.sum()                  # ticks per ns
@@ -84,7 +89,7 @@ def main():
     print('  launch span first entry -> last block end : %7.2f us' % end.max())
     print('  per block (us)                            p10     p50     p90')
     print('  entry after first block               %s' % pct(entry))
-    for k, label in enumerate(GEMM_PHASES if c < 4 else ATT_PHASES):
+    for k, label in enumerate(GEMM_PHASES if c < 4 else (LS_PHASES if c == 7 else ATT_PHASES)):
       if c == 6 and k != 5:
         continue
       print('  %-37s %s' % (label if c != 6 else 'entry -> stores have left', pct(ph[:, k])))
