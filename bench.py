@@ -511,9 +511,11 @@ def main():
       # self-attention output projection's launch -- its ALGORITHMIC work (2 T J D, once) is counted there
       flops['gemm_attn_out'] += flops['gemm_cross_q']
       abytes['gemm_attn_out'] += abytes.get('gemm_cross_q', 0)
-    # dominant kernel = the longest single launch of the step (the class whose template also has
-    # the most algorithmic FLOPs); per-step totals by class are listed in per_class_ms_per_step
-    dom = max((n for n in per_class if n in flops), key=lambda n: per_class[n]['ms_per_launch'])
+    # dominant kernel = the class that carries the most algorithmic FLOP per step (the gated MLP input projection:
+    # 30 % of the step's FLOP and the largest share of its GPU time in the rocprofv3 trace).  NOT "the longest
+    # eager launch": under hipEvents the first launch of a step (in-proj, cold) can outlast it by a microsecond,
+    # which once put a 0.05 GFLOP kernel into this object.  Per-step totals by class: per_class_ms_per_step.
+    dom = max((n for n in per_class if n in flops), key=lambda n: flops[n] * per_class[n]['launches_per_step'])
     event_ms = per_class[dom]['ms_per_launch']
     step_flops = sum(flops[n] * per_class[n]['launches_per_step'] for n in per_class if n in flops)
     prof_entry, prof_src = profile_roofline(dom, args)

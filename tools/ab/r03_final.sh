@@ -1,7 +1,7 @@
 #!/bin/bash
 # Final GPU session of round 3 on the shipped binary: full -m gpu suite + smoke (the green log of HEAD), profiling round
 # (kernel trace + PMC passes, stamped with the library hash), default bench line, 8-song kernel trace.
-TAG=${1:-r03o}
+TAG=${1:-r03w}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
