@@ -19,7 +19,9 @@ class _StubNative:
     per_launch_us = {'gemm_qkv': 10.0, 'attn_self': 8.0, 'gemm_attn_out': 6.0, 'gemm_cross_q': 5.0, 'attn_cross': 12.0,
                      'gemm_cross_out': 6.0, 'gemm_mlp_in_geglu': 14.0, 'gemm_mlp_out': 12.0}
     out = {k: (v * 1e-3 * 12 * n_steps, 12 * n_steps) for k, v in per_launch_us.items()}
-    for k, v in (('final_proj_f32', 9.0), ('sampler_step', 5.0), ('in_proj_f32', 6.0)):
+    # (in-proj: the cold first launch of a step outlasts the MLP-in launch under eager hipEvents -- it did on the GPU,
+    # profiles/r03w_bench_default.json -- and must still not be picked as the roofline's dominant kernel)
+    for k, v in (('final_proj_f32', 9.0), ('sampler_step', 5.0), ('in_proj_f32', 19.0)):
       out[k] = (v * 1e-3 * n_steps, n_steps)
     return out
 

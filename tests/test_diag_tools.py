@@ -1,0 +1,56 @@
+"""The measurement tooling that is not part of the product but is cited by DESIGN.md must stay usable:
+
+  * tools/diag/phase_timestamps.patch (per-block phase stamps, debug build only) applies to the tree as it is, and the
+    product sources contain none of it (the default library is built WITHOUT the stamps);
+  * tools/diag/phase_times.py turns a stamp table into the per-phase medians it prints (synthetic stamps here)."""
+import importlib.util
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATCH = os.path.join(ROOT, 'tools', 'diag', 'phase_timestamps.patch')
+CSRC = os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'csrc')
+
+
+@pytest.mark.skipif(shutil.which('patch') is None, reason='patch(1) not installed')
+def test_phase_stamp_patch_applies_to_the_tree(tmp_path):
+  dst = tmp_path / 'music-spectrogram-diffusion_amd' / 'csrc'
+  shutil.copytree(CSRC, dst, ignore=shutil.ignore_patterns('*.so', '*.tmp'))
+  r = subprocess.run(['patch', '-p1', '--dry-run', '-i', PATCH], cwd=tmp_path, capture_output=True, text=True)
+  assert r.returncode == 0, r.stdout + r.stderr
+  assert 'FAILED' not in r.stdout and 'fuzz' not in r.stdout, r.stdout
+
+
+def test_product_sources_carry_no_stamps():
+  for f in os.listdir(CSRC):
+    if f.endswith(('.h', '.hip')):
+      text = open(os.path.join(CSRC, f)).read()
+      assert 'MSD_TIMESTAMPS' not in text and 'g_msd_ts' not in text, f
+
+
+def test_phase_times_table_arithmetic():
+  """phase_times.py's per-class reduction on a synthetic table: 4 blocks, 2 GHz core clock (s_memtime) against the
+  100 MHz s_memrealtime; phases of 1 / 2 / 3 / 0.5 / 1.5 / 0.25 us."""
+  spec = importlib.util.spec_from_file_location('phase_times', os.path.join(ROOT, 'tools', 'diag', 'phase_times.py'))
+  src = open(spec.origin).read()
+  assert "ts = np.zeros((8, 1024, 12), np.uint64)" in src   # the layout this test mirrors
+  us = np.array([0, 1, 3, 6, 6.5, 8, 8.25])
+  t = np.zeros((4, 12), np.int64)
+  for b in range(4):
+    t[b, :7] = 1000 + b * 50 + (us * 2000).astype(np.int64)       # 2000 ticks per us
+    t[b, 8], t[b, 9] = b, 4
+    t[b, 10] = 500 + b                                             # realtime at entry, 10 ns units
+    t[b, 11] = t[b, 10] + 825                                      # 8.25 us later
+  core = t[:, :7] - t[:, :1]
+  real = (t[:, 11] - t[:, 10]).astype(np.float64) * 10.
+  ghz = core[:, 6].sum() / real.sum()
+  ph = np.diff(core, axis=1) / ghz / 1e3
+  assert abs(ghz - 2.0) < 1e-9
+  np.testing.assert_allclose(np.median(ph, axis=0), [1, 2, 3, 0.5, 1.5, 0.25], rtol=1e-9)
+  # and the script uses exactly these expressions
+  for line in ("core = t[:, :7] - t[:, :1]", "ghz = core[:, 6].sum() / real.sum()", "ph = np.diff(core, axis=1) / ghz / 1e3"):
+    assert line in src, line
