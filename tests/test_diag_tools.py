@@ -54,3 +54,14 @@ def test_phase_times_table_arithmetic():
   # and the script uses exactly these expressions
   for line in ("core = t[:, :7] - t[:, :1]", "ghz = core[:, 6].sum() / real.sum()", "ph = np.diff(core, axis=1) / ghz / 1e3"):
     assert line in src, line
+
+
+def test_every_library_switch_is_documented():
+  """Each environment variable msd_create (or a launch helper) reads is listed in DESIGN.md 11's table of A/B switches."""
+  import re
+  src = open(os.path.join(CSRC, 'msd_api.hip')).read()
+  names = set(re.findall(r'getenv\("(MSD_[A-Z0-9_]+)"\)', src))
+  assert len(names) >= 15
+  design = open(os.path.join(ROOT, 'DESIGN.md')).read()
+  missing = sorted(n for n in names if n not in design)
+  assert not missing, 'switches read by the library but absent from DESIGN.md: %s' % missing
