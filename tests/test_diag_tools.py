@@ -65,3 +65,33 @@ def test_every_library_switch_is_documented():
   design = open(os.path.join(ROOT, 'DESIGN.md')).read()
   missing = sorted(n for n in names if n not in design)
   assert not missing, 'switches read by the library but absent from DESIGN.md: %s' % missing
+
+
+def test_tools_do_not_import_the_oracle():
+  """tools/ is measurement tooling around the product: like the product it must not reach into oracle/ (directly or
+  through tests.helpers, which imports it)."""
+  import re
+  bad = []
+  for d, _, files in os.walk(os.path.join(ROOT, 'tools')):
+    for f in files:
+      if f.endswith('.py'):
+        text = open(os.path.join(d, f)).read()
+        if re.search(r'^\s*(from|import)\s+(oracle|tests)\b', text, re.M):
+          bad.append(os.path.relpath(os.path.join(d, f), ROOT))
+  assert not bad, bad
+
+
+def test_diag_inputs_equal_the_test_helpers():
+  """tools/diag/_inputs.py restates two helpers of tests/helpers.py (without the oracle import): same arrays."""
+  import sys
+  import msd_amd
+  from tests import helpers
+  sys.path.insert(0, os.path.join(ROOT, 'tools', 'diag'))
+  import _inputs
+  spec = msd_amd.config.preset('tiny_context', num_steps=3)
+  a, b = helpers.make_batch(spec, batch=2), _inputs.make_batch(spec, batch=2)
+  assert a.keys() == b.keys()
+  for k in a:
+    np.testing.assert_array_equal(a[k], b[k])
+  for x, y in zip(helpers.make_noise(spec, batch=2), _inputs.make_noise(spec, batch=2)):
+    np.testing.assert_array_equal(x, y)

@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 import msd_amd
-from tests import helpers
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _inputs as helpers   # (not tests.helpers: that imports oracle/)
 
 out = []
 for preset, nb in (('base_with_context', 1), ('small', 1), ('base_with_context', 8)):

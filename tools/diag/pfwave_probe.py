@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 import msd_amd
-from tests import helpers
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _inputs as helpers   # (not tests.helpers: that imports oracle/)
 spec = msd_amd.config.preset('base_with_context', num_steps=3)
 model = msd_amd.InferenceModel('synthetic:0', spec)
 batch = helpers.make_batch(spec)

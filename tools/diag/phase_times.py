@@ -30,7 +30,8 @@ import torch
 
 import msd_amd
 from msd_amd import native
-from tests import helpers
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _inputs as helpers   # (not tests.helpers: that imports oracle/)
 
 CLASSES = ['GEMM, BN = 128 (gated MLP-in, last layer: 64 x 128 at one song, 128 x 128 batched)',
            'GEMM, BN = 96 (one song: QKV, last layer, 64 x 96; batched: the last 128 x 96 launch of the step)',
