@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 3   /* 3: MSD_ERR_RANGE; distinct values for the bfloat16-plane precisions; msd_op_gemm_h16 */
+#define MSD_AMD_ABI_VERSION 4   /* 4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
+                                      replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
+                                      NO environment variable.  3: MSD_ERR_RANGE; distinct bfloat16-plane precisions */
 
 typedef struct msd_model msd_model; /* opaque */
 
@@ -63,8 +65,8 @@ typedef enum msd_precision {
   MSD_PREC_F16 = 0,    /* one IEEE-half plane per operand (v_mfma_f32_*_f16), fp32 accumulate: fast, not parity-grade */
   MSD_PREC_F16X3 = 1,  /* operands split hi + lo half planes (22 significand bits), 3 MFMAs per product
                           (hi.hi + hi.lo + lo.hi): float32-class results -- the parity mode and the default.
-                          In the decoder's attentions the QUERY side (Q in q.k^T, the softmax weights in P.V)
-                          enters as one plane, the memory side (K, V) as hi + lo: 2 MFMAs per product there.
+                          The query side of the decoder's attentions may run on one plane: msd_config.attn_q_planes /
+                          attn_p_planes.
                           Weights must satisfy |w| < 128 (packed times 2^9; checked by msd_finalize_weights ->
                           MSD_ERR_UNSUPPORTED); activations |x| <= 65504 (checked on every conversion ->
                           MSD_ERR_RANGE from the call that saw it). */
@@ -141,12 +143,16 @@ typedef struct msd_config {
   int32_t cross_attend_sum;       /* T5Config.decoder_cross_attend_style: 0 = "concat_encodings" (every shipped
                                      gin), 1 = "sum_cross_attends" (the dataclass default, network.py:199-216:
                                      one cross-attention module per encoding, outputs summed) */
-  /* ABI 3 */
-  int32_t attn_query_planes;      /* planes of the QUERY side (Q in q.k^T, softmax weights in P.V) of the decoder's
-                                     attentions in the two-plane modes: 0 = the library's choice (1 with half
-                                     planes, 2 with bfloat16 planes), 1, or 2 = hi + lo like the memory side
-                                     (K, V), which always keeps both.  1 is 2.5 % faster and 1.05 - 1.25x the
-                                     float32 oracle's error after 1000 steps */
+  /* ABI 4: the query side of the decoder's attentions in the two-plane modes (the memory side -- K, V -- always keeps
+   * hi + lo).  0 = the library's choice (DESIGN.md 3 says which and why), 1 = one 16-bit plane, 2 = hi + lo. */
+  int32_t attn_q_planes;          /* Q in q.k^T: one plane perturbs a logit by ~|s| 2^-12 -- fine for O(1) logits,
+                                     not for sharp (trained) attention */
+  int32_t attn_p_planes;          /* the softmax weights in P.V: one plane = 2^-12 relative on each weight, whatever
+                                     the logits */
+  int32_t graph_steps;            /* DDPM steps captured per hipGraph (0 = the library's choice, 8) */
+  int32_t weight_prefetch;        /* producers warm the next GEMM's weights: 0 = the library decides from the model's
+                                     size (on when a step streams more than the 256 MB Infinity Cache holds), 1 = on,
+                                     2 = off */
 } msd_config;
 
 const char* msd_version(void);
@@ -193,8 +199,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id,
                const float* init_z_dev, const float* noise_dev, float* out_dev,
                void* stream);
 
-/* Drop the captured hipGraph of the DDPM step; the next msd_sample captures it again (launch-time
- * tunables such as the MSD_XCD_* environment switches are read during capture: tools/sweep_xcd.py). */
+/* Drop the captured hipGraph of the DDPM step; the next msd_sample captures it again. */
 int msd_reset_graph(msd_model* m);
 
 /* One decoder call of the scan body: pred_fn(z, time=(i+1)/N, include_conditioning)
@@ -242,8 +247,8 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
                      const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
                      int heads, void* stream); /* q [n_q, heads*64] (n_q % 64 == 0), k/v [n_keys, heads*64] (n_keys % 32 == 0) */
 /* The same with the query-side single-plane switches of the two-plane modes: qp bit 0 = Q enters q.k^T as ONE
- * 16-bit plane, bit 1 = the softmax weights enter P.V as one plane (K and V always keep hi + lo).  The decoder's
- * attentions run with qp = 3 under MSD_PREC_F16X3; msd_op_attention is qp = 0. */
+ * 16-bit plane (msd_config.attn_q_planes = 1), bit 1 = the softmax weights enter P.V as one plane
+ * (attn_p_planes = 1); K and V always keep hi + lo.  msd_op_attention is qp = 0. */
 int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* k_dev,
                         const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
                         int heads, void* stream);
@@ -263,8 +268,8 @@ int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_de
 /* x_out = x_in + a.w1 ; h_out = (RMSNorm(x_out; gamma) (.) (film_scale+1) + film_bias) . w2
  * (layers.py:632-666 + the Dense that follows).  folded=1: the decoder's folded-norm epilogues
  * (EpiResidualNorm producer, row-scale + tabulated bias.W consumer); folded=2: the same with the producer as the
- * 4-way split-K launch the decoder's MLP output projection runs on (m % 64, d % 128, k % 256 == 0 and
- * (m/64)(d/128) 4 <= compute units; launched three times over the same arrival counters); folded=0: separate norm kernel.
+ * 4-way split-K launch of the experiments build (tools/ubench/exp; MSD_ERR_UNSUPPORTED in the product library);
+ * folded=0: separate norm kernel.
  * film_scale_dev / film_bias_dev [D] may both be NULL (plain RMSNorm).
  *   x [m,d]  a [m,k]  w1 [k,d]  gamma [d]  w2 [d,n]  x_out [m,d]  h_out [m,n]; m,k,d,n % 64 == 0 */
 int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_dev,

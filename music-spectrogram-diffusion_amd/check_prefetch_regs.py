@@ -10,7 +10,7 @@ from the load is checked, both sides of every conditional branch.  (Round 2's sc
 the same thing for a single straight-line epilogue but flags the OTHER arm of a kernel with two bodies --
 gemm_h16_dual_kernel -- whose code merely follows in the listing.)
 
-usage: python tools/check_prefetch_regs.py /tmp/msd.s"""
+usage: python music-spectrogram-diffusion_amd/check_prefetch_regs.py /tmp/msd.s"""
 import re
 import sys
 

@@ -104,6 +104,11 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     }
   }
   constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2), QS = (QP & 4) != 0;
+#if MSD_TIMESTAMPS
+  const int ts_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  constexpr int ts_cls = QB == 1 ? 4 : 5;
+#endif
+  MSD_TS_BEGIN(ts_cls, ts_blk)
   constexpr int kRows = 32 * QB;                 // query rows per block
   constexpr int JPW = 16 / (QB * kAttKG);        // K (and V^T) DMA instructions per wave, plane and stage
   constexpr float NEG = -1e30f;
@@ -186,6 +191,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (s < nst) MSD_A_ISSUE(s, s)
+  MSD_TS_AT(ts_cls, ts_blk, 1)
 
   f32x16 o0, o1;
 #pragma unroll
@@ -212,6 +218,9 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     }
     __builtin_amdgcn_s_barrier();   // stage st visible everywhere; compute(st-1) done everywhere
     __builtin_amdgcn_sched_barrier(0);
+#if MSD_TIMESTAMPS
+    if (st == 0) { MSD_TS_AT(ts_cls, ts_blk, 2) }
+#endif
     // The DMA of stage st+NS-1 goes into the slot compute(st-1) just released.  It is issued
     // AFTER this wave's S^T MFMAs (below): as the first thing after the barrier the eight
     // waves' DMA instructions queue up at the CU's address unit and hold back the MFMAs
@@ -319,6 +328,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
+  MSD_TS_AT(ts_cls, ts_blk, 3)
   PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_h16.h WeightPrefetch)
   {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -343,6 +353,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     mine[32 * kAttOLD + 32 + q_lane] = l_run;
   }
   __syncthreads();
+  MSD_TS_AT(ts_cls, ts_blk, 4)
   // QB query blocks x 32 q x 8 groups of 8 d = QB * 256 work items = one per thread
   {
     const int item = tid;
@@ -386,6 +397,8 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     }
   }
   prefetch_done(pf_keep);
+  MSD_TS_AT(ts_cls, ts_blk, 5)
+  MSD_TS_END(ts_cls, ts_blk, gridDim.x * gridDim.y * gridDim.z)
 }
 
 // Finish a key-split attention: out[row][head*64 + d] = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m)
@@ -394,6 +407,7 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   const int item = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d group)
   const int d0 = (item & 7) * 8, head = (item >> 3) % heads, row = (item >> 3) / heads;
   if (row >= p.total_rows) return;
+  MSD_TS_BEGIN(6, blockIdx.x)
   float mt = -1e30f;
   for (int ks = 0; ks < p.ksplit; ++ks)
     mt = fmaxf(mt, p.part_ml[(((size_t)ks * p.total_rows + row) * heads + head) * 2]);
@@ -416,6 +430,8 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   RangeCheck rc;
   store_h16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v, rc);
   rc.commit(p.sat, p.sat_tag);
+  MSD_TS_AT(6, blockIdx.x, 5)
+  MSD_TS_END(6, blockIdx.x, gridDim.x)
 }
 
 template <int NP, int NS, int QB, int QP>
@@ -440,8 +456,10 @@ inline hipError_t attention_prepare() {
   MSD_ATT_PREP(1, 0) MSD_ATT_PREP(2, 0)
   if constexpr (NP == 2) {
     MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3)
+#if MSD_EXPERIMENTS   // QP bit 2 (un-normalised queries) exists for the hoisted query projection only
     MSD_ATT_PREP(1, 4) MSD_ATT_PREP(2, 4) MSD_ATT_PREP(1, 5) MSD_ATT_PREP(2, 5) MSD_ATT_PREP(1, 6) MSD_ATT_PREP(2, 6)
     MSD_ATT_PREP(1, 7) MSD_ATT_PREP(2, 7)
+#endif
   }
 #undef MSD_ATT_PREP
   return e;
@@ -473,14 +491,16 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
   if constexpr (NP == 2) {
-    switch ((p.qp & 3) | (p.q_ssq ? 4 : 0)) {
+    switch ((p.qp & 3) | (kExperiments && p.q_ssq ? 4 : 0)) {
       case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
       case 2: launch_attention_qp<NP, 2>(p, heads, segs, stream); break;
       case 3: launch_attention_qp<NP, 3>(p, heads, segs, stream); break;
+#if MSD_EXPERIMENTS
       case 4: launch_attention_qp<NP, 4>(p, heads, segs, stream); break;
       case 5: launch_attention_qp<NP, 5>(p, heads, segs, stream); break;
       case 6: launch_attention_qp<NP, 6>(p, heads, segs, stream); break;
       case 7: launch_attention_qp<NP, 7>(p, heads, segs, stream); break;
+#endif
       default: launch_attention_qp<NP, 0>(p, heads, segs, stream); break;
     }
   } else {

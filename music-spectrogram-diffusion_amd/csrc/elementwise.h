@@ -144,7 +144,9 @@ __device__ __forceinline__ float sampler_update(const SamplerParams& p, const fl
     x0 = c[kCoefX0Scale] * (z - eps * c[kCoefX0Eps]);
   }
   if (p.clip_x0) {
-    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    // jnp.clip semantics: a NaN stays a NaN (fminf / fmaxf would turn it into a bound and hide a poisoned input --
+    // the half-plane range flag sees Inf but not NaN: v_max3_f32 drops NaN operands)
+    x0 = x0 < -1.0f ? -1.0f : (x0 > 1.0f ? 1.0f : x0);
     eps = c[kCoefEpsScale] * (z - x0 * c[kCoefEpsX0]);
   }
   float zs;
@@ -160,17 +162,16 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   const float* c = p.coef + (size_t)i * kCoefCount;
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx < p.n) {
-    const float4 zz = *reinterpret_cast<const float4*>(p.z + idx);
-    const float4 ec = *reinterpret_cast<const float4*>(p.eps + idx);
-    float4 eu = make_float4(0.f, 0.f, 0.f, 0.f), nz = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.passes == 2) eu = *reinterpret_cast<const float4*>(p.eps + p.n + idx);
-    if (!p.ddim && i != 0) nz = *reinterpret_cast<const float4*>(*p.noise_slot + (size_t)i * p.n + idx);
-    const float zin[4] = {zz.x, zz.y, zz.z, zz.w}, e0[4] = {ec.x, ec.y, ec.z, ec.w};
-    const float e1[4] = {eu.x, eu.y, eu.z, eu.w}, nn[4] = {nz.x, nz.y, nz.z, nz.w};
-    float out[4];
+    // native vectors (not float4 structs copied into arrays: those went through 20 bytes of scratch)
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(p.z + idx);
+    const f32x4 ec = *reinterpret_cast<const f32x4*>(p.eps + idx);
+    f32x4 eu = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
+    if (p.passes == 2) eu = *reinterpret_cast<const f32x4*>(p.eps + p.n + idx);
+    if (!p.ddim && i != 0) nz = *reinterpret_cast<const f32x4*>(*p.noise_slot + (size_t)i * p.n + idx);
+    f32x4 out;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zin[k], e0[k], e1[k], nn[k]);
-    *reinterpret_cast<float4*>(p.z + idx) = make_float4(out[0], out[1], out[2], out[3]);
+    for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zz[k], ec[k], eu[k], nz[k]);
+    *reinterpret_cast<f32x4*>(p.z + idx) = out;
     if (p.z_hi) {
       uint32_t h[2], l[2];
       RangeCheck rc;
@@ -202,7 +203,9 @@ __global__ void build_g_kernel(const float* film, const float* gamma, float* g, 
 
 // step_ptr[0] <- step_ptr[1]  (double-buffered scan index: the sampler writes the
 // next index to slot 1 while other blocks of the same launch may still read slot 0)
+#if MSD_EXPERIMENTS   // only the unfolded (separate-norm) step needs it: the folded step double-buffers the index
 __global__ void advance_step_kernel(int* step_ptr) { step_ptr[0] = step_ptr[1]; }
+#endif
 
 // scale_to_features (audio_codecs.py:176-183) on the final x0
 __global__ void unscale_kernel(const float* x0, float* out, int n, float fmin, float fmax) {

@@ -171,6 +171,45 @@ __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk,
   }
 }
 
+// Phase timestamps (debug builds only: -DMSD_TIMESTAMPS=1, tools/diag/phase_times.py): every block of a GEMM
+// launch records s_memtime at entry, when K-tile 0 has landed, behind the main loop and behind the epilogue; the
+// last launch of each tile shape stays in g_msd_ts and is read back through msd_debug_timestamps().  Compiled out
+// of the product (the default build is bit-identical with and without this block).
+#ifndef MSD_TIMESTAMPS
+#define MSD_TIMESTAMPS 0
+#endif
+#if MSD_TIMESTAMPS
+// classes: 0 BN = 128 | 1 BN = 96 | 2 other 64-row tiles | 3 narrow tiles | 4 attention QB = 1 | 5 attention QB = 2 | 6 merge
+// fields : 0 entry | 1 prologue issued | 2 first tile landed | 3 loop end | 4 slab + stats | 5 epilogue issued |
+//          6 stores left | 8 XCC_ID | 9 grid | 10 / 11 s_memrealtime at entry / end
+constexpr int kTsClasses = 8, kTsBlocks = 1024, kTsFields = 12;
+__device__ unsigned long long g_msd_ts[kTsClasses][kTsBlocks][kTsFields];
+template <int BM, int BN> constexpr int ts_class() { return BN == 128 ? 0 : (BN == 96 ? 1 : (BM == 64 ? 2 : 3)); }
+#define MSD_TS_AT(CLS, BLK, FIELD)                                                                       \
+  if (threadIdx.x == 0 && (BLK) < kTsBlocks) g_msd_ts[CLS][BLK][FIELD] = __builtin_amdgcn_s_memtime();
+#define MSD_TS_BEGIN(CLS, BLK)                                                                           \
+  MSD_TS_AT(CLS, BLK, 0)                                                                                 \
+  if (threadIdx.x == 0 && (BLK) < kTsBlocks) g_msd_ts[CLS][BLK][10] = __builtin_amdgcn_s_memrealtime();
+#define MSD_TS_END(CLS, BLK, GRID)                                                                       \
+  {                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    MSD_TS_AT(CLS, BLK, 6)                                                                               \
+    if (threadIdx.x == 0 && (BLK) < kTsBlocks) {                                                         \
+      unsigned xcc_;                                                                                     \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                \
+      g_msd_ts[CLS][BLK][8] = xcc_ & 0xf;                                                                \
+      g_msd_ts[CLS][BLK][9] = (unsigned long long)(GRID);                                                \
+      g_msd_ts[CLS][BLK][11] = __builtin_amdgcn_s_memrealtime();                                         \
+    }                                                                                                    \
+  }
+#define MSD_TS_STAMP(BM_, BN_, FIELD) MSD_TS_AT((ts_class<BM_, BN_>()), blockIdx.x, FIELD)
+#else
+#define MSD_TS_AT(CLS, BLK, FIELD)
+#define MSD_TS_BEGIN(CLS, BLK)
+#define MSD_TS_END(CLS, BLK, GRID)
+#define MSD_TS_STAMP(BM_, BN_, FIELD)
+#endif
+
 struct GemmParams {
   const h16_t* A[2];
   const h16_t* B[2];
@@ -299,6 +338,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / SK / kGemmBK;
+  MSD_TS_BEGIN((ts_class<BM, BN>()), blockIdx.x)
   // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
 #pragma unroll
   for (int s = 0; s < NS; ++s)
@@ -312,6 +352,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   const int n0e = n0 + (SK > 1 ? ks * BNE : 0);   // first column of the epilogue's share
   epi.template prefetch<BM, BNE, CP>(aux, m0, n0e, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
+  MSD_TS_STAMP(BM, BN, 1)
 
   // Fragment reads of one 32-wide half (kk) of the K-tile in ring slot BUF (prologue only; the
   // loop uses the per-slot forms below)
@@ -446,6 +487,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  MSD_TS_STAMP(BM, BN, 2)
   MSD_D_READ(fa0, fb0, 0, 0)
   __builtin_amdgcn_s_waitcnt(0xC07F);
   int buf = 0;  // LDS ring slot of tile kt
@@ -468,6 +510,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_D_ISSUE
 #undef MSD_A_SRC
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
+  MSD_TS_STAMP(BM, BN, 3)
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   auto store_slab = [&]() {
@@ -487,99 +530,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     store_slab();
     epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
     __syncthreads();
+    MSD_TS_STAMP(BM, BN, 4)
     epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+    MSD_TS_STAMP(BM, BN, 5)
+    MSD_TS_END((ts_class<BM, BN>()), blockIdx.x, gridDim.x)
   } else {
-    // ---- split-K exchange: a reduce-scatter among the SK blocks of this tile --------------------------------
-    // Every block holds a full BM x BN partial.  It keeps the BNE columns it owns, hands the other SK-1 column
-    // groups to their owners through the workspace, and after ONE arrival barrier among the SK blocks sums the
-    // SK partials of its own columns (always in split order 0..SK-1: bit-reproducible) and runs the epilogue on
-    // them.  The SK blocks of a tile are laid out on ONE XCD (kernel wrapper), so plain stores land in the L2 the
-    // readers are served from and the L1-bypassing (sc1) LDS-DMA reads them back without any cache maintenance
-    // -- the pattern tools/ubench/xcd_sync.hip validated (500 rounds x 256 blocks, 0 stale words).  The block ->
-    // XCD placement is an OBSERVATION, not a contract: every block publishes its XCC_ID, every block compares its
-    // group's, and a mismatch (or a barrier timeout) raises p.sk_err, which fails the msd_* call that ran it.
-    constexpr int LDE = BNE + kSlabPad;
-    constexpr int Q4 = BM * BNE / 4;                       // float4 items of one column group
-    constexpr int SLAB_BYTES = (BM * LDS_LD + BM) * 4;
-    constexpr int STAGE_OFF = (SLAB_BYTES + 1023) / 1024 * 1024;         // SK-1 staged partials [BM][BNE], 1 KiB aligned
-    constexpr int SLABE_OFF = STAGE_OFF + (SK - 1) * BM * BNE * 4;       // the reduced tile [BM][LDE] (+ BM floats)
-    static_assert(SLABE_OFF + (BM * LDE + BM) * 4 <= NS * STAGE_BYTES, "split-K staging must fit the operand LDS");
-    static_assert((BM * BNE * 4) % 1024 == 0 && ((SK - 1) * BM * BNE * 4 / 1024) % 4 == 0, "whole DMA instructions per wave");
-    store_slab();
-    __syncthreads();
-    float* const part = p.sk_part + (size_t)tile_id * SK * SK * BM * BNE;
-    for (int it = tid; it < (SK - 1) * Q4; it += 256) {
-      const int qq = it / Q4, r = it % Q4;
-      const int q = qq + (qq >= ks ? 1 : 0);               // destination split (owner of these columns)
-      const int m = r / (BNE / 4), c4 = r % (BNE / 4);
-      const float4 v = *reinterpret_cast<const float4*>(slab + m * LDS_LD + q * BNE + c4 * 4);
-      *reinterpret_cast<float4*>(part + ((size_t)(q * SK + ks) * BM + m) * BNE + c4 * 4) = v;
-    }
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xf;
-    if (tid == 0) __hip_atomic_store(p.sk_xcc + tile_id * SK + ks, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my stores have reached L2
-    __syncthreads();
-    if (tid == 0) {
-      unsigned* cnt = p.sk_cnt + tile_id;
-      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (old / SK + 1) * SK;
-      int spins = 0;
-      while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (++spins > kSplitSpinLimit) { atomicAdd(p.sk_err, 1); break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      // placement words of the group: SK independent L1-bypassing loads (all in flight together), then compared
-      unsigned seen[SK];
-#pragma unroll
-      for (int q = 0; q < SK; ++q)
-        seen[q] = __hip_atomic_load(p.sk_xcc + tile_id * SK + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool same = true;
-#pragma unroll
-      for (int q = 0; q < SK; ++q) same = same && seen[q] == xcc + 1u;
-      if (!same) atomicAdd(p.sk_err, 1 << 16);
-    }
-    __syncthreads();
-    {  // the SK-1 partials of MY columns: L1-bypassing LDS-DMA, 1 KiB per instruction, dealt over the 4 waves
-      typedef const __attribute__((address_space(1))) void* gp_t;
-      typedef __attribute__((address_space(3))) void* lp_t;
-      constexpr int N_INSTR = (SK - 1) * BM * BNE * 4 / 1024, PER_Q = BM * BNE * 4 / 1024;
-      for (int i = wave; i < N_INSTR; i += 4) {
-        const int qq = i / PER_Q, r = i % PER_Q;
-        const int q = qq + (qq >= ks ? 1 : 0);             // source split
-        const char* src = reinterpret_cast<const char*>(part + (size_t)(ks * SK + q) * BM * BNE) + r * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(smem + STAGE_OFF + i * 1024), 16, 0, 16 /* sc1 */);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the later launch's weights: touched AFTER the partials were requested (vmcnt retires in order), so that the
-    // counted wait below covers the partials and leaves these PF * kPrefetchPerThread touches in flight
-    if constexpr (!kPfWave) {
-      prefetch_weights<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0], pf_keep);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * kPrefetchPerThread) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    float* const slabE = reinterpret_cast<float*>(smem + SLABE_OFF);
-    const float* const stage = reinterpret_cast<const float*>(smem + STAGE_OFF);
-    for (int it = tid; it < Q4; it += 256) {
-      const int m = it / (BNE / 4), c4 = it % (BNE / 4);
-      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int q = 0; q < SK; ++q) {                       // split order, whoever owns the columns
-        float4 v;
-        if (q == ks) v = *reinterpret_cast<const float4*>(slab + m * LDS_LD + ks * BNE + c4 * 4);
-        else v = *reinterpret_cast<const float4*>(stage + ((size_t)(q - (q > ks ? 1 : 0)) * BM + m) * BNE + c4 * 4);
-        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-      }
-      *reinterpret_cast<float4*>(slabE + m * LDE + c4 * 4) = sum;
-    }
-    epi.template stats<BM, LDE>(slabE, m0, tid, aux);
-    __syncthreads();
-    epi.template run<BM, BNE, LDE>(slabE, m0, n0e, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+#if MSD_EXPERIMENTS
+#include "../../tools/ubench/exp/gemm_splitk_exchange.inc"
+#else
+    static_assert(SK == 1, "split-K is an experiments-build kernel (tools/ubench/exp)");
+#endif
   }
   prefetch_done(pf_keep);
 }
@@ -613,71 +573,6 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(Gemm
   }
   if (bn >= nbn || bm >= nbm) return;
   gemm_tile<NP, BM, BN, NS, Epi, 0, PF>(p, epi, bm, bn, smem);
-}
-
-// Split-K variant for the one GEMM of the step whose K is long and whose N is short (the MLP output projection,
-// M x D x F: 64 x 32 tiles over 32 K-tiles spent 9 of their 15.5 us streaming (64 + 32) rows per K-tile; SK blocks of
-// a 64 x 128 tile stream (64 + 128) rows over K / SK).  Grid = 8 XCDs x (tiles per XCD x SK) blocks, all resident
-// at once (host checks tiles * SK <= CUs: the blocks of a tile wait for each other).  Block b runs on XCD b % 8
-// (observed placement; verified in the kernel): XCD (xr, xc) of the xcd_rows x (8 / xcd_rows) grid owns the row
-// tiles [xr nbm / RX, +nbm / RX) x column tiles [xc nbn / CX, +nbn / CX); slot = b / 8 = (tile of that XCD, split).
-template <int NP, int BM, int BN, int NS, int SK, class Epi, int PF = kPfNone>
-__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_splitk_kernel(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (kPfWave && PF != kPfNone) {
-    if (threadIdx.x >= 256) {
-      prefetch_wave<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0]);
-      return;
-    }
-  }
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  const int RX = p.xcd_rows, CX = 8 / RX;
-  const int nbm_x = nbm / RX, nbn_x = nbn / CX;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int g = slot / SK, ks = slot % SK;
-  if (g >= nbm_x * nbn_x) return;
-  const int bm = (xcd / CX) * nbm_x + g / nbn_x, bn = (xcd % CX) * nbn_x + g % nbn_x;
-  gemm_tile<NP, BM, BN, NS, Epi, 0, PF, SK>(p, epi, bm, bn, smem, ks, bm * nbn + bn);
-}
-
-// Two independent GEMMs of one tile shape in ONE launch (no data flows between them): blocks [0, n2) run problem 2,
-// the rest problem 1.  Used by the HOISTED cross-attention query
-// projection (msd_api.hip decoder_layers): its first half rides on the QKV launch's idle CUs, its second half on the
-// launch of the self-attention output projection -- a launch boundary less per layer.  Each problem keeps its own
-// XCD-aware tile map (n2 is a multiple of 8, so a block's XCD is the same in the launch-wide and in the
-// problem-local numbering).
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2, int PF = kPfNone>
-__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n2) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (kPfWave && PF != kPfNone) {
-    if (threadIdx.x >= 256) {   // prefetch wave: every block of the launch takes part
-      prefetch_wave<PF>(p2.pf, blockIdx.x, gridDim.x, p1.B[0]);
-      return;
-    }
-  }
-  const bool second = (int)blockIdx.x < n2;
-  const GemmParams& p = second ? p2 : p1;
-  const int b = second ? (int)blockIdx.x : (int)blockIdx.x - n2;
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  const int RX = p.xcd_rows, CX = 8 / RX;
-  const int xcd = b & 7, tt = b >> 3;
-  const int nbm_x = (nbm + RX - 1) / RX, nbn_x = (nbn + CX - 1) / CX;
-  int bm, bn;
-  if (p.xcd_walk_n) {
-    bm = (tt / nbn_x) * RX + xcd / CX; bn = (tt % nbn_x) * CX + xcd % CX;
-  } else {
-    bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
-  }
-  if (bn >= nbn || bm >= nbm) return;
-  // In-epilogue prefetch builds (MSD_PF_WAVE=0): the touches ride on problem 2's blocks only (p2.pf_nblk = n2): ONE
-  // prefetch site in the kernel, in the arm behind which nothing but its own epilogue runs --
-  // tools/check_prefetch_regs.py follows the control flow, and the structurised two-arm layout of this kernel
-  // re-tests its condition after the first arm, which no text tool can see through.
-  if (!second) {
-    gemm_tile<NP, BM, BN, NS, Epi1, 0, kPfNone>(p1, e1, bm, bn, smem);
-    return;
-  }
-  gemm_tile<NP, BM, BN, NS, Epi2, 0, PF>(p2, e2, bm, bn, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -892,53 +787,6 @@ struct EpiStoreH16 {
   }
 };
 
-// C (row-major 16-bit planes) = acc + addend[m][n] (fp32): the second half of the hoisted cross-attention query
-// projection adds the first half, which an earlier launch left in float32.  The addend tile is prefetched into the
-// aux LDS region like the residual tile of EpiResidualNorm (BN == 32), so the epilogue issues no global load.
-template <int NP>
-struct EpiAddStoreH16 {
-  h16_t* out[2];
-  int ldc;
-  const float* addend;
-  int ld_add;
-  template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 : 0; }
-  template <int BM, int BN, int CP = 0>
-  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    if (BN != 32) return;
-    __builtin_assume(aux != nullptr);
-    for (int i = wave; i < BM / 8; i += 4)
-      __builtin_amdgcn_global_load_lds(
-          (aux_gptr_t)(addend + (size_t)(m0 + 8 * i + (lane >> 3)) * ld_add + n0 + (lane & 7) * 4),
-          (aux_lptr_t)(aux + i * 1024), 16, 0, CP);
-  }
-  template <int BM, int LD>
-  __device__ void stats(float*, int, int, const char*) const {}
-  template <int BM, int BN, int LD>
-  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
-                      SatFlag sf = SatFlag()) const {
-    const bool pre = aux && BN == 32;
-    typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
-    RangeCheck rc;
-    for (int item = tid; item < BM * BN / 8; item += 256) {
-      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
-      float v[8];
-      tile_row8<LD>(s0, m, n, v);
-      f32x4 a, b;
-      if (pre) {
-        lds_cf32x4 xs = (lds_cf32x4)(aux);
-        a = xs[(m * BN + n) / 4]; b = xs[(m * BN + n) / 4 + 1];
-      } else {
-        const float* pa = addend + (size_t)(m0 + m) * ld_add + n0 + n;
-        a = *reinterpret_cast<const f32x4*>(pa); b = *reinterpret_cast<const f32x4*>(pa + 4);
-      }
-      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
-      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
-      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
-    }
-    rc.commit(sf.p, sf.tag);
-  }
-};
-
 // Fused QKV (or K|V) projection: columns [0, v_start) -> row-major bf16 `qk`
 // [M, ld_qk]; columns [v_start, N) -> V^T planes [seg][N - v_start][vt_ld] with the
 // key axis permuted per 16 (seg = m / seg_len, key = m % seg_len).
@@ -1074,7 +922,7 @@ struct EpiResidualNorm {
     const int step = *step_ptr;
     if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)step * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
-    if (g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * 128 + 2048, BN * 4, lane);
+    if (kExperiments && g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * 128 + 2048, BN * 4, lane);
   }
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
@@ -1102,7 +950,7 @@ struct EpiResidualNorm {
       sq += __shfl_xor(sq, 1, 64);   // 4 consecutive lanes = one 32-column group of one row
       sq += __shfl_xor(sq, 2, 64);
       if ((item & 3) == 0) ssq[(size_t)row * tiles + col / 32] = sq;
-      if (g2 != nullptr && row < y2_rows) {
+      if (kExperiments && g2 != nullptr && row < y2_rows) {
         float4 g0, g1;
         LG2(n, col, g0, g1);
         const float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w,
@@ -1204,7 +1052,7 @@ struct EpiInProj {
       const float4 g1 = *reinterpret_cast<const float4*>(gs + col + 4);
       float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w,
                     v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
-      if (g2 != nullptr) {   // pass 0 = the conditional rows
+      if (kExperiments && g2 != nullptr) {   // pass 0 = the conditional rows
         const float4 c0 = *reinterpret_cast<const float4*>(g2 + col), c1 = *reinterpret_cast<const float4*>(g2 + col + 4);
         const float u[8] = {v[0] * c0.x, v[1] * c0.y, v[2] * c0.z, v[3] * c0.w,
                             v[4] * c1.x, v[5] * c1.y, v[6] * c1.z, v[7] * c1.w};
@@ -1303,6 +1151,12 @@ struct EpiGeglu {
   }
 };
 
+// Which epilogues ever carry a weight prefetch (one kernel instantiation per PF value): the encoders' plain residual
+// and the fp32 store never do, so their PF = 1 twins are not built.
+template <class Epi> struct epi_may_prefetch : std::true_type {};
+template <> struct epi_may_prefetch<EpiResidual> : std::false_type {};
+template <> struct epi_may_prefetch<EpiStoreF32> : std::false_type {};
+
 template <int NP, int BM, int BN, int NS, class Epi>
 constexpr int gemm_h16_dma_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN>(); }
 
@@ -1318,10 +1172,12 @@ inline hipError_t gemm_h16_dma_prepare_one() {
 template <int NP, int BM, int BN, int NS, class Epi>
 inline hipError_t gemm_h16_dma_prepare() {
   hipError_t e = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 0>(), r;
-  if constexpr (NP == 2) {   // the single-plane mode never prefetches
+  if constexpr (NP == 2 && (kExperiments || epi_may_prefetch<Epi>::value)) {   // the single-plane mode never prefetches
     if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 1>()) != hipSuccess) e = r;
+#if MSD_EXPERIMENTS          // the product carries at most ONE prefetch target per launch
     if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 2>()) != hipSuccess) e = r;
     if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 3>()) != hipSuccess) e = r;
+#endif
   }
   return e;
 }
@@ -1337,10 +1193,12 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipSt
 #define MSD_LAUNCH_PF(PF_) \
   hipLaunchKernelGGL((gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256 + pf_threads(PF_)), smem, stream, p, epi)
   const int npf = NP == 2 ? prefetch_kind(p.pf) : 0;
-  if constexpr (NP == 2) {
-    if (npf == 1) MSD_LAUNCH_PF(1);
-    else if (npf == 2) MSD_LAUNCH_PF(2);
-    else if (npf >= 3) MSD_LAUNCH_PF(3);
+  if constexpr (NP == 2 && (kExperiments || epi_may_prefetch<Epi>::value)) {
+#if MSD_EXPERIMENTS
+    if (npf == 2) { MSD_LAUNCH_PF(2); return hipGetLastError(); }
+    if (npf >= 3) { MSD_LAUNCH_PF(3); return hipGetLastError(); }
+#endif
+    if (npf >= 1) MSD_LAUNCH_PF(1);   // product: the first target only
     else MSD_LAUNCH_PF(0);
   } else {
     MSD_LAUNCH_PF(0);
@@ -1349,79 +1207,15 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipSt
   return hipGetLastError();
 }
 
-// ---- dual launch ----------------------------------------------------------------------------------------------
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
-constexpr int gemm_h16_dual_smem() {
-  constexpr int a = gemm_h16_dma_smem<NP, BM, BN, NS, Epi1>(), b = gemm_h16_dma_smem<NP, BM, BN, NS, Epi2>();
-  return a > b ? a : b;
-}
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
-inline hipError_t gemm_h16_dual_prepare() {
-  constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
-  if (smem < 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  return e != hipSuccess ? e : r;
-}
-inline int gemm_grid_blocks(const GemmParams& p, int BM, int BN) {
-  const int rx = p.xcd_rows, cx = 8 / rx;
-  return 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
-}
-// p1 / e1: the first problem; p2 / e2: the second.  The weight prefetch target (at most one) is taken from p1.pf.
-template <int NP, int BM, int BN, int NS, class Epi1, class Epi2>
-inline hipError_t launch_gemm_h16_dual(const GemmParams& p1, const Epi1& e1, GemmParams p2, const Epi2& e2, hipStream_t stream) {
-  constexpr int smem = gemm_h16_dual_smem<NP, BM, BN, NS, Epi1, Epi2>();
-  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM, BN, NS, Epi1, Epi2>();
-  if (attr != hipSuccess) return attr;
-  const int n1 = gemm_grid_blocks(p1, BM, BN), n2 = gemm_grid_blocks(p2, BM, BN);
-  p2.pf = p1.pf;
-  p2.pf_nblk = n2;
-  if (NP == 2 && prefetch_kind(p1.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 1>), dim3(n1 + n2), dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n2);
-  else
-    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM, BN, NS, Epi1, Epi2, 0>), dim3(n1 + n2), dim3(256), smem, stream, p1, e1, p2, e2, n2);
-  return hipGetLastError();
-}
-
-// ---- split-K launch -------------------------------------------------------------------------------------------
-template <int NP, int BM, int BN, int NS, int SK, class Epi>
-constexpr int gemm_h16_splitk_smem() { return NS * NP * (BM + BN) * 128 + Epi::template aux_bytes<BM, BN / SK>(); }
-
-// (rows, columns) of the XCD grid for a split-K launch: as many column groups as divide the column tiles
-inline int splitk_xcd_rows(int nbm, int nbn) {
-  for (int cx = 4; cx >= 1; cx >>= 1)
-    if (nbn % cx == 0 && nbm % (8 / cx) == 0) return 8 / cx;
-  return 0;   // no grid fits: the caller keeps the plain kernel
-}
-
-// floats / words of workspace a split-K GEMM of M x N needs
-template <int BM, int BN, int SK>
-inline size_t splitk_part_floats(int M, int N) { return (size_t)(M / BM) * (N / BN) * SK * BM * BN; }
-
-template <int NP, int BM, int BN, int NS, int SK, class Epi>
-inline hipError_t gemm_h16_splitk_prepare() {
-  constexpr int smem = gemm_h16_splitk_smem<NP, BM, BN, NS, SK, Epi>();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  return e != hipSuccess ? e : r;
-}
-
-// p.xcd_rows must come from splitk_xcd_rows(); p.sk_* must be set; (M/BM) * (N/BN) * SK blocks must be co-resident
-template <int NP, int BM, int BN, int NS, int SK, class Epi>
-inline hipError_t launch_gemm_h16_splitk(const GemmParams& p, const Epi& epi, hipStream_t stream) {
-  constexpr int smem = gemm_h16_splitk_smem<NP, BM, BN, NS, SK, Epi>();
-  static const hipError_t attr = gemm_h16_splitk_prepare<NP, BM, BN, NS, SK, Epi>();
-  if (attr != hipSuccess) return attr;
-  const int grid = (p.M / BM) * (p.N / BN) * SK;   // = 8 XCDs x tiles per XCD x SK
-  if (prefetch_kind(p.pf) >= 1)
-    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 1>), dim3(grid), dim3(256 + pf_threads(1)), smem, stream, p, epi);
-  else
-    hipLaunchKernelGGL((gemm_h16_splitk_kernel<NP, BM, BN, NS, SK, Epi, 0>), dim3(grid), dim3(256), smem, stream, p, epi);
-  return hipGetLastError();
-}
-
 }  // namespace msd
+
+#if MSD_EXPERIMENTS
+#include "../../tools/ubench/exp/gemm_h16_exp.h"
+#endif
+
+#if MSD_TIMESTAMPS   // debug builds only (tools/diag/phase_times.py); the product library has no such symbol
+extern "C" int msd_debug_timestamps(unsigned long long* host_out) {   // [kTsClasses][kTsBlocks][kTsFields]
+  if (hipDeviceSynchronize() != hipSuccess) return 5;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(msd::g_msd_ts), sizeof(msd::g_msd_ts)) == hipSuccess ? 0 : 5;
+}
+#endif

@@ -16,20 +16,25 @@
 
 #include "../../include/msd_amd.h"
 #include "attention.h"
-#include "chain.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_h16.h"
-#include "gemm_h16_pair.h"
-#include "gemm_h16_wide.h"
-#include "gemm_h16_ls.h"
 #include "gemm_f32.h"
+#if MSD_EXPERIMENTS   // rejected kernels + environment switches of the A/B build (tools/ubench/exp/README.md); never in the product
+#include "../../tools/ubench/exp/chain.h"
+#include "../../tools/ubench/exp/gemm_h16_pair.h"
+#include "../../tools/ubench/exp/gemm_h16_wide.h"
+#include "../../tools/ubench/exp/gemm_h16_ls.h"
+#endif
 
 using namespace msd;
 
 namespace {
 
 constexpr int kHeadDim = 64;
+// Library default of the decoder attentions' query side under MSD_PREC_F16X3 (msd_config.attn_q_planes /
+// attn_p_planes = 0): see DESIGN.md 3, "sharp attention".
+constexpr int kDefaultQPlanes = 1, kDefaultPPlanes = 1;
 
 enum KClass { KC_NORM = 0, KC_GEMM_QKV, KC_ATTN_SELF, KC_GEMM_ATTN_OUT, KC_GEMM_CROSS_Q,
               KC_ATTN_CROSS, KC_GEMM_CROSS_OUT, KC_GEMM_MLP_IN, KC_GEMM_MLP_OUT,
@@ -73,8 +78,10 @@ struct DecLayerW {
   Planes wq_cross[2];   // [J, D]
   Planes wkv_cross[2];  // [2J, D] (k|v)
   Planes wo_cross[2];   // [D, J]
+#if MSD_EXPERIMENTS
   // hoisted query projection of module 0 (decoder_layers): W^T of Wo_self . diag(gamma_cross) . Wq, [J, J]
   Planes w2;
+#endif
   MlpW mlp;
 };
 struct EncoderW {
@@ -131,7 +138,7 @@ struct msd_model {
   float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
   float *att_part_o = nullptr, *att_part_ml = nullptr;  // key-split attention partials
   int cross_ksplit = 1;        // key split of the cross-attention at batch 1 (allocation bound)
-  bool cross_ksplit_fixed = false;   // MSD_CROSS_KSPLIT given: use it at every batch size
+  bool cross_ksplit_fixed = false;   // experiments build, MSD_CROSS_KSPLIT given: use it at every batch size
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
@@ -155,56 +162,41 @@ struct msd_model {
 
   hipGraphExec_t graph_exec = nullptr;
   int graph_batch = 0;
-  int graph_steps = 8;              // DDPM steps per graph launch (MSD_GRAPH_STEPS; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
+  int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
   hipGraphExec_t graph_exec1 = nullptr;   // single-step graph for N mod graph_steps
-  bool dual_chain = false;          // CFG passes as two concurrent graph branches (MSD_DUAL_CHAIN)
+  bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
+  int cus = 0;                 // compute units of the device
+  float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
+  // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
+  // 2 = the softmax weights enter P.V as one plane); from msd_config.attn_q_planes / attn_p_planes, DESIGN.md 3
+  int att_qp_self = 0, att_qp_cross = 0;
+#if MSD_EXPERIMENTS
+  // ---- A/B switches of the experiments build, read from the environment by exp_read_env() (docs/history.md) ----
+  bool dual_chain = false;     // CFG passes as two concurrent graph branches (MSD_DUAL_CHAIN)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool fold_norm = true;  // MSD_FOLD_NORM=0: separate RMSNorm kernels (A/B and debugging)
-  // XCD-resident chains (chain.h): MLP-in -> MLP-out -> next layer's QKV in one launch (MSD_CHAIN=1: on)
-  bool chain_mlp = false;
-  bool prefetch = true;        // producers warm the next GEMM's weights in L2 (MSD_PREFETCH=0: off)
-  // prefetch-wave builds: the QKV launch also warms the layer's cached cross-attention K / V^T.  OFF: measured +2.5 %
-  // step time on the MI355X (profiles/r03g_env_ab.log: 1099-1105 vs 1073-1075 ms per segment): cross-attention wins
-  // 1 us, but the QKV launch loses 2.2 -- its compute waves' first s_barrier also waits for the prefetch wave, whose 36
-  // touches take longer to retire than the first K-tile takes to land.  MSD_PF_KV=1 turns it on.
-  bool pf_kv = false;
-  // batched path (128-row tiles): K-tiles of 32, two blocks resident per CU (gemm_h16_pair.h; MSD_BIG_PAIR=0/1)
-  bool big_pair = false;
-  // batched path, gated-MLP input: 256 x 128 tiles on eight waves (gemm_h16_wide.h; MSD_BIG_WIDE=0/1)
-  bool big_wide = false;
-  // batched path, gated-MLP input: 256 x 128 tiles, four multiplying + four loader waves (gemm_h16_ls.h; MSD_BIG_LS=0/1)
-  bool big_ls = false;
-  int cus = 0;                 // compute units of the device (chain grid = one block per CU)
+  bool fold_norm = true;       // MSD_FOLD_NORM=0: separate RMSNorm kernels
+  bool chain_mlp = false;      // XCD-resident chain MLP-in -> MLP-out -> next QKV (chain.h; MSD_CHAIN)
+  int chain_mode = 0;          // MSD_CHAIN's value: 1 = round 2's chain, 2 = with pre-staged weights (round 4)
+  bool pf_kv = false;          // QKV launch also warms the layer's cached cross-attention K / V^T (MSD_PF_KV)
+  bool big_pair = false, big_wide = false, big_ls = false;   // batched tile variants (MSD_BIG_PAIR / _WIDE / _LS)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
-  float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
-  // Hoisted cross-attention query projection (decoder_layers).  OFF by default: parity-green (tests/test_gpu_model.py,
-  // hoisted vs plain order 3e-7) and it removes one launch per layer, but measured 0 .. +1 % SLOWER per step on the
-  // MI355X in both forms (profiles/r03f_env_ab.log: K-concatenated, one dual launch; profiles/r03j_hoist_ab.log: two
-  // stages) -- the dual out-projection launch grows by what the query projection's own launch took, because its 576
-  // blocks no longer fit the 512 resident slots.  MSD_HOIST_Q=1 turns it on.  Needs the folded norms, the two-plane
-  // mode, one cross-attention module and D % 128 == 0.
-  bool hoist_q = false;
+  bool hoist_q = false;        // hoisted cross-attention query projection (MSD_HOIST_Q)
   Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
-  float* qpart = nullptr;      // (x0 (.) gamma_cross) . Wq of the layer, fp32 [Bmax * T, J]: first half of the hoisted projection
-  // Query-side single-plane attention of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q, 2 = P).
-  // Default 3 with half planes in the two-plane mode: 11-bit Q and P planes against K / V kept as hi + lo cost
-  // 1.05 - 1.25x the float32 oracle's own error (small 1000 steps 7.4e-5 vs 6.8e-5; 12-segment chain 0.9 - 1.2x the
-  // float32 oracle at every depth: profiles/r03c_golden_qp3.log) and save 2.2 % of the step (two of six MFMAs per
-  // tile pair, no hi / lo split of P).  bfloat16 planes (8-bit significands) keep all three products: 2.7e-4 there.
-  // MSD_ATT_QP_SELF / MSD_ATT_QP_CROSS = 0..3 override.
-  int att_qp_self = 0, att_qp_cross = 0;
-  // split-K MLP output projection (gemm_h16.h gemm_h16_splitk_kernel).  OFF by default: measured 2.5 % SLOWER per
-  // step than the 64 x 32 tiles on the MI355X (profiles/r03b_env_ab.log: 1168 vs 1140 ms per segment; the exchange
-  // costs more than the shorter K loop wins); MSD_SPLITK=1 turns it on (parity-tested, tests/test_gpu_fused_ops.py)
-  bool splitk = false;
-  int splitk_min_k = 2048;     // K from which the split pays (MSD_SPLITK_MINK)
+  float* qpart = nullptr;      // (x0 (.) gamma_cross) . Wq of the layer, fp32 [Bmax * T, J]
+  bool splitk = false;         // split-K MLP output projection (MSD_SPLITK)
+  int splitk_min_k = 2048;
   float* sk_part = nullptr;    // exchange workspace
-  unsigned* sk_cnt = nullptr;  // [tiles] arrival counters (zeroed at the start of every msd_* call that launches steps)
+  unsigned* sk_cnt = nullptr;  // [tiles] arrival counters
   unsigned* sk_xcc = nullptr;  // [tiles][SK] placement words
-  int* d_sk_err = nullptr;     // low 16 bits: barrier timeouts; from bit 16: groups whose blocks were NOT on one XCD
+  int* d_sk_err = nullptr;
   size_t sk_tiles = 0;
+  int xcd_rows = 2, xcd_walk_n = 1;   // MSD_XCD_ROWS / MSD_XCD_WALK_N
+  int big_m = 2048;                   // MSD_BIG_M
+#else
+  static constexpr bool fold_norm = true;   // the product always folds RMSNorm + FiLM into the GEMM epilogues
+#endif
   unsigned* d_sat = nullptr;   // half-plane range flag: kernel class + 1 of a conversion that saw |x| > 65504 (common.h RangeCheck)
   unsigned* h_sat = nullptr;   // pinned host copy, read after the stream sync that ends msd_encode / msd_sample
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
@@ -228,7 +220,7 @@ int fail(const msd_model* m, int code, const char* fmt, ...) {
     hipError_t _e = (expr);                                                           \
     if (_e != hipSuccess)                                                             \
       return fail(m, MSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                  __FILE__, __LINE__);                                                \
+                  "msd_api.hip", __LINE__); /* not __FILE__: no checkout path in the binary */ \
   } while (0)
 
 template <class Tp>
@@ -255,6 +247,12 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
 // Half-plane range flag (common.h RangeCheck): read it behind a stream sync; a set flag fails the call LOUDLY
 // (round 2 clamped at 65504 and returned MSD_OK with a wrong spectrogram).  The flag is cleared for the next call.
+// arm: every call that ends with check_range() starts with a clean flag (a flag raised on an error path of an earlier
+// call, which returned before its own check, must not be blamed on this one)
+int arm_range(msd_model* m, hipStream_t s) {
+  if (kPlaneSaturates) HIP_TRY(m, hipMemsetAsync(m->d_sat, 0, sizeof(unsigned), s));
+  return MSD_OK;
+}
 int check_range(msd_model* m, hipStream_t s, const char* what) {
   if (!kPlaneSaturates) {
     HIP_TRY(m, hipStreamSynchronize(s));
@@ -274,9 +272,11 @@ int check_range(msd_model* m, hipStream_t s, const char* what) {
 }
 
 
-// In-kernel synchronisation words (split-K arrival counters, chain barriers): fresh for every msd_* call that
-// launches decoder steps, and read back behind the call's final stream sync -- a timed-out wait or a block group
-// that was not placed on one XCD fails THAT call (gemm_h16.h gemm_tile SK > 1, chain.h).
+// In-kernel synchronisation words exist only in the experiments build (split-K arrival counters, chain barriers:
+// fresh for every msd_* call that launches decoder steps, read back behind the call's final stream sync, so that a
+// timed-out wait or a block group that was not placed on one XCD fails THAT call).  The product's kernels never wait
+// for another block of their own launch.
+#if MSD_EXPERIMENTS
 int reset_sync_words(msd_model* m, hipStream_t s) {
   if (m->sk_cnt) {
     HIP_TRY(m, hipMemsetAsync(m->sk_cnt, 0, sizeof(unsigned) * m->sk_tiles, s));
@@ -302,6 +302,10 @@ int check_sync_words(msd_model* m, const char* what) {   // call after the strea
                 "the XCD of their slot; the result of this call is invalid (MSD_CHAIN=0)", what, bad[1] & 0xffff, bad[1] >> 16);
   return MSD_OK;
 }
+#else
+inline int reset_sync_words(msd_model*, hipStream_t) { return MSD_OK; }
+inline int check_sync_words(msd_model*, const char*) { return MSD_OK; }
+#endif
 
 void add_weight(msd_model* m, const std::string& name, int64_t a, int64_t b = -1) {
   Weight w;
@@ -418,10 +422,10 @@ enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3, TK_SQUARE
 // (tools/env_ab.sh): 1 x 8 -> 1.196 ms, 2 x 4 -> 1.167 ms, 4 x 2 -> 1.187 ms; choosing per launch by
 // the bytes each L2 has to fetch (A / rx + B * rx / 8) picked 1 x 8 for the wide GEMMs and was no
 // better than 1 x 8 everywhere.
-void set_xcd_grid(GemmParams& p, int kc, int M, int BM) {
+void set_xcd_grid(const msd_model* m, GemmParams& p, int kc, int M, int BM) {
   int rx = 2, walk_n = 1;
-  if (const char* v = getenv("MSD_XCD_ROWS")) rx = atoi(v) > 0 ? atoi(v) : rx;
-  if (const char* v = getenv("MSD_XCD_WALK_N")) walk_n = atoi(v);
+#if MSD_EXPERIMENTS
+  rx = m->xcd_rows; walk_n = m->xcd_walk_n;
   // per-class override for A/B runs: MSD_XCD_<class name, upper case>="rows,walk", e.g. MSD_XCD_GEMM_QKV=1,0
   char name[64] = "MSD_XCD_";
   size_t n = 8;
@@ -431,6 +435,9 @@ void set_xcd_grid(GemmParams& p, int kc, int M, int BM) {
     int a = 0, b = 0;
     if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0) { rx = a; walk_n = b; }
   }
+#else
+  (void)m; (void)kc;
+#endif
   p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
   p.xcd_walk_n = walk_n;
 }
@@ -442,19 +449,20 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  set_xcd_grid(p, kc, M, BM);
+  set_xcd_grid(c.m, p, kc, M, BM);
   hipError_t e = launch_gemm_h16_dma<NP, BM, BN, NS, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
 
+#if MSD_EXPERIMENTS
 // the same launch on the batched path's co-resident K = 32 tiles (gemm_h16_pair.h)
 template <int NP, int BM, int BN, class Epi>
 void gemm_t_pair(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi) {
   c.begin(kc);
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  set_xcd_grid(p, kc, M, BM);
+  set_xcd_grid(c.m, p, kc, M, BM);
   hipError_t e = launch_gemm_h16_pair<NP, BM, BN, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
@@ -466,7 +474,7 @@ void gemm_t_wide(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int 
   c.begin(kc);
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  set_xcd_grid(p, kc, M, 256);
+  set_xcd_grid(c.m, p, kc, M, 256);
   hipError_t e = launch_gemm_h16_wide<NP, BN, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
@@ -480,11 +488,13 @@ void gemm_t_ls(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ld
   GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
-  set_xcd_grid(p, kc, M, 256);
+  set_xcd_grid(c.m, p, kc, M, 256);
   hipError_t e = launch_gemm_h16_ls<NP, BN, Epi>(p, epi, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
+
+#endif   // MSD_EXPERIMENTS
 
 constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
 
@@ -500,10 +510,14 @@ inline long tile_cost(int M, int N, int BM, int BN) {
 // Batched songs (M = passes * B * T >= big_m_threshold() = 2048): every CU has several tiles anyway, so the tiles
 // grow to 128 x 96/128 (2-deep ring, 128 KiB) -- half the L2->LDS re-reads per MAC
 // (tools/ubench/gemm_bench_big.hip, M = 4096: QKV 85 -> 61 us, MLP-in 114 -> 95, MLP-out 68 -> 48).
+#if MSD_EXPERIMENTS
 inline int big_m_threshold() {   // rows from which the 128-row tiles are used (MSD_BIG_M overrides)
   static const int v = [] { const char* e = getenv("MSD_BIG_M"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
   return v;
 }
+#else
+constexpr int big_m_threshold() { return 2048; }   // rows from which the 128-row tiles are used
+#endif
 
 // The tile a GEMM of kind TK runs on, (BM, BN): ONE rule for the launch below and for whoever prefetches that
 // launch's weights (the prefetcher needs the consumer's column tile and XCD grid).
@@ -543,11 +557,15 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 // the batched test and measured 10 % SLOWER end to end at 8 and 16 songs (profiles/r03m_k32_ab.log: 465 vs 516 and
 // 498 vs 550 mel-frames/s; gated MLP input 1.34 vs 1.13 ms per step): twice the barriers per K and one wave per SIMD
 // at 340 registers cost more than the deeper ring hides.  Not in the product build.
+#if MSD_EXPERIMENTS
 #define MSD_GO_BIG(BM_, BN_)                                                                                          \
   {                                                                                                                   \
     if (c.m->big_pair && K % kPairBK == 0) return gemm_t_pair<NP, BM_, BN_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi); \
     MSD_GO(BM_, BN_, 2);                                                                                              \
   }
+#else
+#define MSD_GO_BIG(BM_, BN_) MSD_GO(BM_, BN_, 2);
+#endif
   if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
       if (t.bm == 128) MSD_GO_BIG(128, 96)
@@ -556,10 +574,12 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     MSD_GO(64, 64, wide_ns(NP));
   } else if constexpr (TK == TK_MLP_IN) {
     if constexpr (NP == 2) {
+#if MSD_EXPERIMENTS
       if (t.bm == 128 && c.m->big_ls && gemm_h16_ls_fits<128>(M, N, K))
         return gemm_t_ls<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf);
       if (t.bm == 128 && c.m->big_wide && gemm_h16_wide_fits<128>(M, N, K))
         return gemm_t_wide<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+#endif
       if (t.bm == 128) MSD_GO_BIG(128, 128)
       if (t.bn == 128) MSD_GO(64, 128, 3);
     }
@@ -577,6 +597,7 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 #undef MSD_GO
 }
 
+#if MSD_EXPERIMENTS
 // The MLP output projection as a 4-way split-K launch on 64 x 128 tiles (gemm_h16.h): only where all blocks of the
 // launch are resident at once (they wait for each other) and K is long enough to pay for the exchange.
 constexpr int kSkBM = 64, kSkBN = 128, kSkNS = 3, kSkSplit = 4;
@@ -599,6 +620,8 @@ void gemm_splitk(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int 
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
 }
+
+#endif   // MSD_EXPERIMENTS
 
 // Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_h16.h PrefetchTarget)
 template <int NP>
@@ -646,9 +669,12 @@ void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const flo
   c.begin(KC_NORM);
   const int vpl = (D + 255) / 256;
 #define NORM_LAUNCH(OUT, VPL) hipLaunchKernelGGL((rmsnorm_film_kernel<OUT, VPL>), grid, block, 0, c.s, p)
+#if MSD_EXPERIMENTS   // fp32 output: the unfolded decoder's final norm only
   if (out_f32) {
     if (vpl <= 1) NORM_LAUNCH(2, 1); else if (vpl <= 2) NORM_LAUNCH(2, 2); else if (vpl <= 3) NORM_LAUNCH(2, 3); else NORM_LAUNCH(2, 4);
-  } else if (NP == 2) {
+  } else
+#endif
+  if (NP == 2) {
     if (vpl <= 1) NORM_LAUNCH(1, 1); else if (vpl <= 2) NORM_LAUNCH(1, 2); else if (vpl <= 3) NORM_LAUNCH(1, 3); else NORM_LAUNCH(1, 4);
   } else {
     if (vpl <= 1) NORM_LAUNCH(0, 1); else if (vpl <= 2) NORM_LAUNCH(0, 2); else if (vpl <= 3) NORM_LAUNCH(0, 3); else NORM_LAUNCH(0, 4);
@@ -1043,6 +1069,7 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
   return check_range(m, s, "msd_encode");   // synchronises
 }
 
+#if MSD_EXPERIMENTS
 // ---- one decoder evaluation (network.py:360-457) on rows [0, P*batch*T) ----------
 // pass 0 is conditional iff `cond0`; pass 1 (if P == 2) is the unconditional CFG pass.
 // Unfolded variant: one RMSNorm(+FiLM) kernel in front of every projection.
@@ -1088,9 +1115,23 @@ void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
   gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
 }
 
+#endif   // MSD_EXPERIMENTS
+
 // The key split exists to fill the chip when heads x query groups alone cannot (48 blocks at one song); with
 // several songs per handle the (head, query group, song) blocks already cover the CUs, and every split costs a
 // partial round trip + the merge launch: split only as far as ~192 blocks need.
+#if MSD_EXPERIMENTS
+template <int NP>
+void chain_launch(Ctx& c, const MlpChainParams<NP>& cp, int /*layer*/) {
+  msd_model* m = c.m;
+  c.begin(KC_CHAIN_MLP);
+  const hipError_t e = ((3 * m->J) % 96 == 0 && (2 * m->J) % 96 == 0) ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s)
+                                                                       : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(KC_CHAIN_MLP);
+}
+#endif
+
 inline int cross_ksplit_for(const msd_model* m, int batch) {
   if (m->cross_ksplit_fixed) return m->cross_ksplit;
   const int blocks = m->H * (m->T / 64) * batch;
@@ -1101,7 +1142,9 @@ inline int cross_ksplit_for(const msd_model* m, int batch) {
 template <int NP>
 void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
   msd_model* m = c.m;
+#if MSD_EXPERIMENTS
   if (!m->fold_norm) { decoder_layers_unfolded<NP>(c, batch, P, cond0); return; }
+#endif
   // `row0`: first activation row of this chain (a multiple of T).  The conditional and the
   // unconditional CFG pass never exchange data inside the decoder (self-attention is per
   // segment), so enqueue_step can run them as two concurrent chains over disjoint row ranges.
@@ -1137,33 +1180,33 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
     return eq;
   };
+#if MSD_EXPERIMENTS
   const bool chain = m->chain_mlp && NP == 2 && M % 64 == 0 && M < big_m_threshold();
+#else
+  constexpr bool chain = false;
+#endif
   for (int l = 0; l < m->Ld; ++l) {
     const DecLayerW& w = m->dec[l];
-    // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection
-    // through one norm kernel; later layers consume the folded-norm planes `y` written by the
-    // previous layer's MLP output projection (inside that layer's chain launch when chains are on).
-    // Weight prefetch plan of a layer (gemm_h16.h WeightPrefetch; every producer warms a LATER GEMM's weights
-    // behind its own epilogue): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional
-    // pass) . cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
+    // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection; later layers consume
+    // the folded-norm planes `y` written by the previous layer's MLP output projection.
+    // Weight prefetch plan of a layer (gemm_h16.h WeightPrefetch; every producer warms a LATER GEMM's weights from a
+    // wave of its own): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional pass) .
+    // cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
     const bool last_layer = (l + 1 == m->Ld);
-    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1).  Its input is
-    // LN(x1) = rstd(x1) (x1 (.) gamma) with x1 = x0 + ao . Wo (x0: the stream entering the layer, ao: the
-    // self-attention output), so
-    //   (x1 (.) gamma) . Wq = (x0 (.) gamma) . Wq  +  ao . (Wo . diag(gamma) . Wq)
-    // and neither term needs the out-projection's result: the first (`qpart`, fp32) is computed by 32 extra blocks
-    // of the QKV launch, which leaves 64 of the 256 CUs idle; the second rides on the launch of the out-projection
-    // and adds the first in its epilogue (gemm_h16_dual_kernel both times); the 1/rms moves onto the logits inside
-    // the attention kernel (AttnParams::q_ssq).  The query projection's own launch (6.2 us of a 93 us layer in round 2)
-    // disappears.  x0 (.) gamma arrives as the planes `yc`, written by whichever epilogue produced x0.
+#if MSD_EXPERIMENTS
+    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1; docs/history.md): 0 .. +1 % step time
     const TileShape tq = pick_tile<NP, TK_QKV>(M, 3 * J, 2 * J);
     const bool hoist = m->hoist_q && cond0 && NP == 2 && row0 == 0 && !chain && tq.bm == 64 && J % tq.bn == 0 && BT % 64 == 0 &&
                        pick_tile<NP, TK_SQUARE>(M, D, 0).bm == kNarrowTile && pick_tile<NP, TK_SQUARE>(BT, J, 0).bm == kNarrowTile;
+#else
+    constexpr bool hoist = false;
+#endif
     if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
       WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
-      // The layer's cached cross-attention K and V^T (14 MB at base, HBM-cold at every step: nothing touched
-      // them since the previous step) can ride on this launch's prefetch waves (MSD_PF_KV=1; off: see pf_kv).
+#if MSD_EXPERIMENTS
+      // The layer's cached cross-attention K and V^T (14 MB at base, HBM-cold at every step) riding on this launch's
+      // prefetch wave (MSD_PF_KV=1): +2.5 % step time, docs/history.md
       if (kPfWave && m->prefetch && m->pf_kv && cond0 && NP == 2 && batch == 1 && m->n_cross == 1 && row0 == 0) {
         const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
         PrefetchTarget tk, tv;
@@ -1178,10 +1221,10 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
           GemmParams p1 = gp<NP>(y, D, w.self.wqkv, D, M, 3 * J, D);
           p1.pf = pf; if (p1.pf.n > 1) p1.pf.n = 1;
           p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_QKV + 1u;
-          set_xcd_grid(p1, KC_GEMM_QKV, M, 64);
+          set_xcd_grid(m, p1, KC_GEMM_QKV, M, 64);
           GemmParams p2 = gp<NP>(m->yc, D, w.wq_cross[0], D, BT, J, D);
           p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
-          set_xcd_grid(p2, KC_GEMM_CROSS_Q, BT, 64);
+          set_xcd_grid(m, p2, KC_GEMM_CROSS_Q, BT, 64);
           EpiStoreF32 ef;
           ef.out = m->qpart; ef.ldc = J;
           c.begin(KC_GEMM_QKV);
@@ -1190,14 +1233,16 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
           if (e != hipSuccess && c.err == hipSuccess) c.err = e;
           c.end(KC_GEMM_QKV);
         }
-      } else {
-        gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
-      }
+      } else
+#endif
+      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
-      const WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D)
-                                : (hoist ? prefetch_of<NP>(m, w.w2, J, J) : prefetch_of<NP>(m, w.wq_cross[0], J, D));
+      WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
+#if MSD_EXPERIMENTS
+      if (cond0 && hoist) pf = prefetch_of<NP>(m, w.w2, J, J);
+#endif
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
     }
@@ -1209,16 +1254,17 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
-    if (hoist) {   // out-projection + second half of the hoisted query projection in one launch (see above)
+#if MSD_EXPERIMENTS
+    if (hoist) {   // out-projection + second half of the hoisted query projection in one launch
       if constexpr (NP == 2) {
         er.g_lo = nullptr; er.g_lo_stride = 0;   // the conditional rows' y = x1 (.) gamma_cross has no reader any more
         GemmParams p1 = gp<NP>(ao, J, w.self.wo, J, M, D, J);
         p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_ATTN_OUT + 1u;
-        set_xcd_grid(p1, KC_GEMM_ATTN_OUT, M, kNarrowTile);
+        set_xcd_grid(m, p1, KC_GEMM_ATTN_OUT, M, kNarrowTile);
         p1.pf = prefetch_of<NP>(m, w.wo_cross[0], D, J);
         GemmParams p2 = gp<NP>(ao, J, w.w2, J, BT, J, J);
         p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
-        set_xcd_grid(p2, KC_GEMM_CROSS_Q, BT, kNarrowTile);
+        set_xcd_grid(m, p2, KC_GEMM_CROSS_Q, BT, kNarrowTile);
         EpiAddStoreH16<NP> es;
         es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // stored un-normalised
         es.addend = m->qpart; es.ld_add = J;
@@ -1227,9 +1273,9 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         if (e != hipSuccess && c.err == hipSuccess) c.err = e;
         c.end(KC_GEMM_ATTN_OUT);
       }
-    } else {
-      gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
-    }
+    } else
+#endif
+    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
@@ -1278,11 +1324,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
+#if MSD_EXPERIMENTS
     if (m->hoist_q && cond0 && !last && row0 == 0) {   // x (.) gamma_cross of the NEXT layer, conditional rows
       eo.y2[0] = m->yc.p[0]; eo.y2[1] = m->yc.p[NP - 1]; eo.g2 = m->dec[l + 1].ln_cross; eo.y2_rows = BT;
     }
     if constexpr (NP == 2) {
-      if (chain) {   // MLP-in -> MLP-out -> QKV of layer l+1: one XCD-resident launch (chain.h)
+      if (chain) {   // MLP-in -> MLP-out -> QKV of layer l+1: one XCD-resident launch (tools/ubench/exp/chain.h)
         MlpChainParams<NP> cp;
         cp.g_in = gp<NP>(y, D, w.mlp.wi, D, M, 2 * F, D);     cp.e_in = eg;
         cp.g_out = gp<NP>(gb, F, w.mlp.wo, F, M, D, F);       cp.e_out = eo;
@@ -1290,18 +1337,16 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         cp.g_qkv = gp<NP>(y, D, m->dec[last ? l : l + 1].self.wqkv, D, M, 3 * J, D);
         cp.e_qkv = qkv_epi(last ? l : l + 1);
         cp.bar = m->d_bar; cp.err = m->d_chain_err;
-        c.begin(KC_CHAIN_MLP);
-        const hipError_t e = ((3 * J) % 96 == 0 && (2 * J) % 96 == 0) ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s)
-                                                                       : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
-        if (e != hipSuccess && c.err == hipSuccess) c.err = e;
-        c.end(KC_CHAIN_MLP);
+        chain_launch<NP>(c, cp, l);
         continue;
       }
     }
+#endif
     {
       const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
       WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+#if MSD_EXPERIMENTS
       if (hoist && !last_layer) pf_qkv.add(weights_target<NP>(m, m->dec[l + 1].wq_cross[0], J, D));   // first half of its hoisted q
       if constexpr (NP == 2) {
         if (splitk_fits(m, NP, M, D, F)) {
@@ -1309,6 +1354,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
           continue;
         }
       }
+#endif
       gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
     }
   }
@@ -1335,19 +1381,25 @@ template <int NP>
 void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   msd_model* m = c.m;
   const int BT = batch * m->T;
+#if MSD_EXPERIMENTS
   if (!m->fold_norm) {
     gemm32(c, KC_IN_PROJ, m->z, m->ND, m->w_in_proj, m->D, BT, m->D, m->ND,
            EpiF32InProj{m->x, m->dec_pos, m->D, m->T, BT, P});
     return;
   }
+#endif
   EpiInProj<NP> ei;
   ei.x = m->x; ei.ldx = m->D; ei.pos = m->dec_pos; ei.T = m->T; ei.pass_rows = BT; ei.passes = P;
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
-  if (m->hoist_q) { ei.y2[0] = m->yc.p[0]; ei.y2[1] = m->yc.p[NP - 1]; ei.g2 = m->dec[0].ln_cross; }
   WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
-  if (m->hoist_q) pf.add(weights_target<NP>(m, m->dec[0].wq_cross[0], m->J, m->D));
+#if MSD_EXPERIMENTS
+  if (m->hoist_q) {
+    ei.y2[0] = m->yc.p[0]; ei.y2[1] = m->yc.p[NP - 1]; ei.g2 = m->dec[0].ln_cross;
+    pf.add(weights_target<NP>(m, m->dec[0].wq_cross[0], m->J, m->D));
+  }
+#endif
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 
@@ -1363,6 +1415,7 @@ void enqueue_step(Ctx& c, int batch) {
   msd_model* m = c.m;
   const int P = m->passes;
   in_proj<NP>(c, batch, P, /*publish_step=*/m->fold_norm);
+#if MSD_EXPERIMENTS
   if (m->dual_chain && P == 2 && m->fold_norm && !m->prof.on) {
     // two concurrent chains (graph branches): conditional rows [0, BT) with cross-attention on
     // the caller's stream, unconditional rows [BT, 2BT) on the side stream; joined for the sampler
@@ -1375,9 +1428,9 @@ void enqueue_step(Ctx& c, int batch) {
     decoder_layers<NP>(c, batch, 1, true, 0);
     if (e == hipSuccess) e = hipStreamWaitEvent(c.s, m->ev_join, 0);
     if (c.err == hipSuccess) c.err = c2.err != hipSuccess ? c2.err : e;
-  } else {
-    decoder_layers<NP>(c, batch, P, true);
-  }
+  } else
+#endif
+  decoder_layers<NP>(c, batch, P, true);
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
@@ -1390,7 +1443,9 @@ void enqueue_step(Ctx& c, int batch) {
   c.begin(KC_SAMPLER);
   sp.step_from_slot1 = m->fold_norm ? 1 : 0;
   hipLaunchKernelGGL(sampler_step_kernel, dim3((sp.n / 4 + 255) / 256), dim3(256), 0, c.s, sp);
+#if MSD_EXPERIMENTS
   if (!m->fold_norm) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
+#endif
   c.end(KC_SAMPLER);
 }
 
@@ -1400,6 +1455,7 @@ void set_func_attrs() {
   (void)attention_prepare<2, 2>();
   (void)prepare_gemms<1>();
   (void)prepare_gemms<2>();
+#if MSD_EXPERIMENTS
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
@@ -1413,7 +1469,40 @@ void set_func_attrs() {
   (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>>();
   (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32>();
   (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32>();
+#endif
 }
+
+#if MSD_EXPERIMENTS
+// The A/B switches of the experiments build (tools/ubench/exp/README.md lists them with what each measured).
+void exp_read_launch_env(msd_model* m) {   // switches that only matter while a step is being captured / launched
+  if (const char* v = getenv("MSD_XCD_ROWS")) m->xcd_rows = atoi(v) > 0 ? atoi(v) : 2;
+  if (const char* v = getenv("MSD_XCD_WALK_N")) m->xcd_walk_n = atoi(v);
+}
+void exp_read_env(msd_model* m) {
+  const msd_config* cfg = &m->cfg;
+  if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
+  if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
+  if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
+  if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
+  if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
+  if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_PAIR")) m->big_pair = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_WIDE")) m->big_wide = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_LS")) m->big_ls = atoi(v) != 0;
+  if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
+  if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
+  if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
+  exp_read_launch_env(m);
+  // chain.h: needs the block -> XCD round robin over 8 XCDs with equal CU counts, the folded norms, two planes and
+  // tile-aligned widths (64 x 128 gated tiles, 64 x 32 output tiles, 64 x 96 or 64 x 64 QKV tiles)
+  const char* v = getenv("MSD_CHAIN");
+  m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && m->NP == 2 && m->cus >= 8 &&
+                 m->cus % 8 == 0 && (2 * cfg->mlp_dim) % 128 == 0 && cfg->emb_dim % 32 == 0 &&
+                 (3 * cfg->num_heads * kHeadDim) % 64 == 0;
+  m->chain_mode = v ? atoi(v) : 0;
+}
+#endif
 
 }  // namespace
 
@@ -1423,7 +1512,7 @@ void set_func_attrs() {
 extern "C" {
 
 const char* msd_version(void) {
-  static const std::string v = std::string("msd_amd 0.4.0 (gfx950, abi 3, ") + kPlaneName + ")";
+  static const std::string v = std::string("msd_amd 0.5.0 (gfx950, abi 4, ") + kPlaneName + ")";
   return v.c_str();
 }
 
@@ -1466,7 +1555,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->n_dims % 64) return bad("n_dims must be a multiple of 64");
   if (cfg->num_steps <= 0 || cfg->max_batch <= 0 || cfg->num_heads <= 0) return bad("non-positive size");
   if (cfg->has_context && cfg->context_length <= 0) return bad("context model needs context_length");
-  if (cfg->attn_query_planes < 0 || cfg->attn_query_planes > 2) return bad("attn_query_planes must be 0 (library default), 1 or 2");
+  if (cfg->attn_q_planes < 0 || cfg->attn_q_planes > 2) return bad("attn_q_planes must be 0 (library default), 1 or 2");
+  if (cfg->attn_p_planes < 0 || cfg->attn_p_planes > 2) return bad("attn_p_planes must be 0 (library default), 1 or 2");
+  if (cfg->graph_steps < 0 || cfg->graph_steps > 64) return bad("graph_steps must be in [0, 64] (0 = library default)");
+  if (cfg->weight_prefetch < 0 || cfg->weight_prefetch > 2) return bad("weight_prefetch must be 0 (by model size), 1 (on) or 2 (off)");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1478,45 +1570,35 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->ND = cfg->n_dims; m->N = cfg->num_steps; m->Ld = cfg->num_decoder_layers; m->Le = cfg->num_encoder_layers;
   m->Bmax = cfg->max_batch;
   m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
-  if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
-  if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
-  if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
-  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
-  if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
-  if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
-  if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
-  if (const char* v = getenv("MSD_BIG_PAIR")) m->big_pair = atoi(v) != 0;
-  if (const char* v = getenv("MSD_BIG_WIDE")) m->big_wide = atoi(v) != 0;
-  if (const char* v = getenv("MSD_BIG_LS")) m->big_ls = atoi(v) != 0;
-  m->att_qp_self = m->att_qp_cross = (kPlaneSaturates && m->NP == 2) ? 3 : 0;
-  if (cfg->attn_query_planes == 2) m->att_qp_self = m->att_qp_cross = 0;
-  else if (cfg->attn_query_planes == 1 && m->NP == 2) m->att_qp_self = m->att_qp_cross = 3;
-  if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
-  if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
-  if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
+  if (cfg->graph_steps > 0) m->graph_steps = cfg->graph_steps;
+  if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
+  {
+    // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
+    // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-
+    // attention study); bfloat16 planes (8-bit significands) always keep both.
+    const bool can_drop = kPlaneSaturates && m->NP == 2;
+    const int qpl = cfg->attn_q_planes ? cfg->attn_q_planes : (can_drop ? kDefaultQPlanes : 2);
+    const int ppl = cfg->attn_p_planes ? cfg->attn_p_planes : (can_drop ? kDefaultPPlanes : 2);
+    m->att_qp_self = m->att_qp_cross = m->NP == 2 ? ((qpl == 1 ? 1 : 0) | (ppl == 1 ? 2 : 0)) : 0;
+  }
   {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       m->cus = cus;
-    // chain.h: needs the block -> XCD round robin over 8 XCDs with equal CU counts, the folded norms, bf16x3 and
-    // tile-aligned widths (64 x 128 gated tiles, 64 x 32 output tiles, 64 x 96 or 64 x 64 QKV tiles)
-    // OFF by default: measured on the MI355X (profiles/r02_chain_ab.log) the chain is 7 % SLOWER per step than
-    // the separate launches -- one row tile per XCD means every XCD streams every weight tile through its own
-    // L2 (the 2 x 4 XCD grid of the stand-alone GEMMs shares each weight tile between 4 row tiles), which costs
-    // what the two saved kernel boundaries win.  MSD_CHAIN=1 turns it on (parity-tested, tests/test_gpu_model.py).
-    const char* v = getenv("MSD_CHAIN");
-    m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && m->NP == 2 && m->cus >= 8 &&
-                   m->cus % 8 == 0 && (2 * cfg->mlp_dim) % 128 == 0 && cfg->emb_dim % 32 == 0 &&
-                   (3 * cfg->num_heads * kHeadDim) % 64 == 0;
   }
+#if MSD_EXPERIMENTS
+  exp_read_env(m);
+#endif
   // encode_impl writes round_up(Lv, 64) token rows and then round_up(Cv, 64) context rows from row Lv
   m->S_pad = round_up(m->L, 64) + round_up(m->C, 64);
   // decoder_cross_attend_style (network.py:199-235): with one encoding both styles are the same module
   m->n_cross = (cfg->cross_attend_sum && cfg->has_context) ? 2 : 1;
   m->key_off[0] = 0; m->key_off[1] = round_up(m->L, 64);
-  if (m->n_cross == 2 && !m->fold_norm) return bad("sum_cross_attends needs the folded-norm path (MSD_FOLD_NORM=1)");
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
+#if MSD_EXPERIMENTS
+  if (m->n_cross == 2 && !m->fold_norm) return bad("sum_cross_attends needs the folded-norm path (MSD_FOLD_NORM=1)");
   m->hoist_q = m->hoist_q && m->fold_norm && m->NP == 2 && m->n_cross == 1 && m->D % 128 == 0 && !m->dual_chain && !m->chain_mlp;
+#endif
   declare_weights(m);
   *out = m;
   set_func_attrs();
@@ -1534,14 +1616,18 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
   TRY(palloc(m, &m->zp, (size_t)m->Bmax * T * m->ND));
+#if MSD_EXPERIMENTS
   if (m->hoist_q) {
     TRY(palloc(m, &m->yc, (size_t)m->Bmax * T * D));
     TRY(dalloc(m, &m->qpart, (size_t)m->Bmax * T * J));
   }
+#endif
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
   m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
+#if MSD_EXPERIMENTS
   if (const char* v = getenv("MSD_CROSS_KSPLIT")) { m->cross_ksplit = atoi(v) > 0 ? atoi(v) : 1; m->cross_ksplit_fixed = true; }
+#endif
   TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
   TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
   TRY(palloc(m, &m->h, Mmax * D));
@@ -1559,10 +1645,11 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->z, (size_t)m->Bmax * T * m->ND));
   TRY(dalloc(m, &m->d_noise_slot, 1));
   TRY(dalloc(m, &m->d_step, 2));
-  TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
-  TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_absmax, 1));
   TRY(dalloc(m, &m->d_sat, 1));
+#if MSD_EXPERIMENTS
+  TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
+  TRY(dalloc(m, &m->d_chain_err, 1));
   TRY(dalloc(m, &m->d_sk_err, 1));
   if (D % kSkBN == 0 && Mmax % kSkBM == 0) {
     m->sk_tiles = (Mmax / kSkBM) * (size_t)(D / kSkBN);
@@ -1572,6 +1659,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
       TRY(dalloc(m, &m->sk_xcc, m->sk_tiles * kSkSplit));
     }
   }
+#endif
   HIP_TRY(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_sat), sizeof(unsigned), hipHostMallocDefault));
   *m->h_sat = 0;
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
@@ -1602,9 +1690,11 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   HIP_TRY(m, hipEventCreate(&m->prof.e0));
   HIP_TRY(m, hipEventCreate(&m->prof.e1));
   HIP_TRY(m, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+#if MSD_EXPERIMENTS
   HIP_TRY(m, hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
   HIP_TRY(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIP_TRY(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+#endif
   return MSD_OK;
 }
 
@@ -1615,9 +1705,11 @@ void msd_destroy(msd_model* m) {
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+#if MSD_EXPERIMENTS
   if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+#endif
   if (m->noise_own) (void)hipFree(m->noise_own);
   if (m->h_sat) (void)hipHostFree(m->h_sat);
   for (void* p : m->allocs) (void)hipFree(p);
@@ -1686,6 +1778,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross[e], 0, 0))) return rc;
     }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
+#if MSD_EXPERIMENTS
     if (m->hoist_q) {
       // q' = (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  (x0 (.) gamma) . Wq + ao . (Wo . diag(gamma) . Wq):
       // the second matrix in float32 on the exact-fp32 MFMA, then packed like any other weight
@@ -1707,6 +1800,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       HIP_TRY(m, e);
       HIP_TRY(m, es);
     }
+#endif
   }
   m->dec_final_ln = W(m, "decoder/decoder_norm/scale");
   m->w_spec_out = W(m, "decoder/spec_out_dense/kernel");
@@ -1731,7 +1825,11 @@ int msd_finalize_weights(msd_model* m, void* stream) {
                               (size_t)2 * m->F * D + (size_t)D * m->F) * planes;
     const size_t kv = (size_t)m->Ld * m->Bmax * m->S_pad * J * 2 * planes;
     const size_t per_step = per_layer * m->Ld + kv;
-    if (!getenv("MSD_PREFETCH")) m->prefetch = per_step > ((size_t)256 << 20);
+    bool decided = m->cfg.weight_prefetch != 0;
+#if MSD_EXPERIMENTS
+    if (getenv("MSD_PREFETCH")) decided = true;
+#endif
+    if (!decided) m->prefetch = per_step > ((size_t)256 << 20);
   }
   HIP_TRY(m, hipStreamSynchronize(s));
   {  // half planes hold kWScale * w: |w| must stay below 65504 / kWScale (common.h)
@@ -1765,6 +1863,7 @@ int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_
   }
   for (int32_t t : tok_h)
     if (t < 0 || t >= m->cfg.vocab_size) return fail(m, MSD_ERR_INVALID_ARGUMENT, "token id %d outside [0, %d)", t, m->cfg.vocab_size);
+  if (int rc0 = arm_range(m, s)) return rc0;
   int rc = m->NP == 2 ? encode_impl<2>(m, batch, tok_h.data(), ctx_dev, mask_h.data(), s)
                       : encode_impl<1>(m, batch, tok_h.data(), ctx_dev, mask_h.data(), s);
   if (rc) return rc;
@@ -1798,6 +1897,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   }
   const int64_t n = (int64_t)batch * m->T * m->ND;
   const bool ddpm = m->cfg.sampler == MSD_SAMPLER_DDPM;
+  if (int rc0 = arm_range(m, s)) return rc0;
   if (init_z_dev) {
     HIP_TRY(m, hipMemcpyAsync(m->z, init_z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   } else {
@@ -1875,7 +1975,10 @@ int msd_reset_graph(msd_model* m) {
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
   m->graph_batch = 0;
-  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps (unset: keep the choice of msd_finalize_weights)
+#if MSD_EXPERIMENTS
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps
+  exp_read_launch_env(m);
+#endif
   return MSD_OK;
 }
 
@@ -1889,6 +1992,7 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)batch * m->T * m->ND;
   const int st[2] = {step_index, step_index};
+  if (int rc0 = arm_range(m, s)) return rc0;
   HIP_TRY(m, hipMemcpyAsync(m->d_step, st, sizeof(st), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipMemcpyAsync(m->z, z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (int rc = reset_sync_words(m, s)) return rc;
@@ -1956,6 +2060,7 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   if (n_steps < 1 || n_steps > m->N) return fail(m, MSD_ERR_INVALID_ARGUMENT, "n_steps outside [1, N]");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)batch * m->T * m->ND;
+  if (int rc0 = arm_range(m, s)) return rc0;
   int rc = msd_fill_normal(1, 0, 0, m->z, n, s);
   if (rc) return rc;
   split_z(m, n, s);
@@ -1984,8 +2089,8 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
     if (m->NP == 2) enqueue_step<2>(c, batch); else enqueue_step<1>(c, batch);
   }
   m->prof.on = false;
-  HIP_TRY(m, hipStreamSynchronize(s));
-  if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "profile run failed: %s", hipGetErrorString(c.err));
+  if (c.err != hipSuccess) { (void)hipStreamSynchronize(s); return fail(m, MSD_ERR_HIP, "profile run failed: %s", hipGetErrorString(c.err)); }
+  if (int rc2 = check_range(m, s, "msd_profile_steps")) return rc2;   // synchronises; the timed steps ran with the flag armed
   if (int rc2 = check_sync_words(m, "msd_profile_steps")) return rc2;
   for (int k = 0; k < MSD_MAX_KERNEL_CLASSES; ++k) {
     ms_out[k] = k < KC_COUNT ? m->prof.ms[k] : 0.0;
@@ -2269,7 +2374,10 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     GemmParams p1 = gp<2>(a, K, w1, K, M, D, K);
     p1.xcd_rows = 2; p1.xcd_walk_n = 1;
     fl.arm(p1);
-    if (folded == 2) {   // the producer as the decoder's 4-way split-K launch (gemm_h16_splitk_kernel)
+    if (folded == 2) {   // the producer as the 4-way split-K launch of the experiments build (gemm_h16_splitk_kernel)
+#if !MSD_EXPERIMENTS
+      return MSD_ERR_UNSUPPORTED;
+#else
       int cus = 0, dev = 0;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2286,6 +2394,7 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
         if (rep) (void)hipMemcpyAsync(x_out_dev, x_in_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s);
         e = launch_gemm_h16_splitk<2, kSkBM, kSkBN, kSkNS, kSkSplit>(p1, er, s);
       }
+#endif
     } else if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, 32, 4>(p1, er, s);
     EpiStoreF32 ef;
     ef.out = h_out_dev; ef.ldc = N;

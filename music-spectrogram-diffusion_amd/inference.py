@@ -75,7 +75,8 @@ class _ModelInfo:
 
 
 def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec,
-                      batch_size: int, precision: str, attention_query_planes: Optional[int] = None) -> native.MsdConfig:
+                      batch_size: int, precision: str, attention_query_planes=None, graph_steps: int = 0,
+                      weight_prefetch: Optional[bool] = None) -> native.MsdConfig:
   t5, d = spec.t5, spec.diffusion
   # Everything the kernels fix by construction is validated here with the
   # reference's own error type (ValueError; msd_amd.h msd_config comment).
@@ -148,9 +149,18 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
   cfg.train_schedule_start, cfg.train_schedule_stop = float(ts.start or 0.0), float(ts.stop or 0.0)
   cfg.train_schedule_num_steps = int(ts.num_steps or 0)
   cfg.cross_attend_sum = int(t5.decoder_cross_attend_style == 'sum_cross_attends')
-  if attention_query_planes not in (None, 0, 1, 2):
-    raise ValueError('attention_query_planes must be None, 1 or 2')
-  cfg.attn_query_planes = int(attention_query_planes or 0)
+  # query side of the decoder's attentions: one number for both Q (in q.k^T) and the softmax weights (in P.V), or a
+  # (q_planes, p_planes) pair; None / 0 = the library's choice
+  qp = attention_query_planes
+  if not isinstance(qp, (tuple, list)):
+    qp = (qp, qp)
+  if len(qp) != 2 or any(v not in (None, 0, 1, 2) for v in qp):
+    raise ValueError('attention_query_planes must be None, 1, 2 or a (q_planes, p_planes) pair of those')
+  cfg.attn_q_planes, cfg.attn_p_planes = int(qp[0] or 0), int(qp[1] or 0)
+  if not 0 <= int(graph_steps) <= 64:
+    raise ValueError('graph_steps must be in [0, 64] (0 = library default)')
+  cfg.graph_steps = int(graph_steps)
+  cfg.weight_prefetch = 0 if weight_prefetch is None else (1 if weight_prefetch else 2)
   return cfg
 
 
@@ -186,7 +196,8 @@ class InferenceModel(object):
 
   def __init__(self, checkpoint_path, gin_config: Union[str, config_lib.ModelSpec],
                batch_size: int = 1, precision: str = 'f16x3', device: Optional[int] = None,
-               range_fallback: bool = False, attention_query_planes: Optional[int] = None):
+               range_fallback: bool = True, attention_query_planes=None, graph_steps: int = 0,
+               weight_prefetch: Optional[bool] = None):
     """Args mirror inference.py:71-88.
 
     gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
@@ -197,13 +208,15 @@ class InferenceModel(object):
       other library build), 'f16' / 'bf16' (one plane, fastest; do NOT meet the bar).
     device: HIP device index (default: torch's current device).
     attention_query_planes: planes of the query side of the decoder's attentions in the hi + lo modes (msd_config
-      attn_query_planes): None = the library's choice -- ONE plane with half planes ('f16x3': the memory side K / V
-      keeps hi + lo; 2.5 % faster, 1.05 - 1.25x the float32 oracle's error over 1000 steps), two with bfloat16
-      planes; 2 = all three products everywhere (what the short-chain float32-class tests run on).
+      attn_q_planes / attn_p_planes): None = the library's choice; 1 or 2 for both Q (in q.k^T) and
+      the softmax weights (in P.V), or a (q_planes, p_planes) pair.  The memory side (K, V) always keeps hi + lo.
+    graph_steps: DDPM steps captured per hipGraph (0 = the library's choice, 8).
+    weight_prefetch: None = the library decides from the model's size; True / False force it.
     range_fallback: what to do when an activation leaves the range of the half planes (|x| > 65504; the
       library detects it and fails the call with native.RangeError -- the reference is float32 and has no such
-      limit): False (default) lets the error out; True switches this model to 'bf16x3' (bfloat16 planes:
-      float32's exponent range, twice the rounding error), once and for good, and repeats the call.
+      limit): True (default) switches this model to 'bf16x3' (bfloat16 planes: float32's exponent range, twice
+      the rounding error), once and for good, with a RuntimeWarning, and repeats the call -- a valid workload
+      never fails; False lets the error out.
     """
     import torch  # device memory + streams only
     if isinstance(gin_config, config_lib.ModelSpec):
@@ -218,6 +231,7 @@ class InferenceModel(object):
     self.precision = precision
     self.range_fallback = bool(range_fallback)
     self.attention_query_planes = attention_query_planes
+    self.graph_steps, self.weight_prefetch = graph_steps, weight_prefetch
 
     self.sequence_length = dict(spec.task_feature_lengths)
     self.inputs_length = self.sequence_length['inputs']
@@ -283,7 +297,7 @@ class InferenceModel(object):
         else:
           params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
         cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision,
-                                self.attention_query_planes)
+                                self.attention_query_planes, self.graph_steps, self.weight_prefetch)
         nm = native.NativeModel(cfg)   # the library build (plane format) follows from cfg.precision
         self._stream = torch.cuda.Stream(device=self.device)
         nm.load_weights(params, stream=self._stream.cuda_stream)

@@ -26,6 +26,7 @@ MSD_PREC_F16 = 0      # one IEEE-half plane per operand
 MSD_PREC_F16X3 = 1    # hi + lo half planes, three MFMAs per product (the parity mode, the default)
 MSD_PREC_BF16 = 2     # one bfloat16 plane                       } libmsd_amd_bf16.so; msd_create of the other
 MSD_PREC_BF16X3 = 3   # hi + lo bfloat16 planes                  } build answers MSD_ERR_UNSUPPORTED
+ABI_VERSION = 4        # MSD_AMD_ABI_VERSION of include/msd_amd.h (tests/test_abi.py)
 MSD_SAMPLER_DDPM = 0
 MSD_SAMPLER_DDIM = 1
 MAX_KERNEL_CLASSES = 16
@@ -72,7 +73,7 @@ MODEL_OUTPUTS = {'eps': MSD_OUTPUT_EPS, 'x0': MSD_OUTPUT_X0, 'v': MSD_OUTPUT_V}
 
 
 class MsdConfig(ctypes.Structure):
-  """msd_config of include/msd_amd.h (ABI 3), field for field."""
+  """msd_config of include/msd_amd.h (ABI 4), field for field."""
   _fields_ = [(n, ctypes.c_int32) for n in (
       'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
       'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
@@ -85,7 +86,8 @@ class MsdConfig(ctypes.Structure):
       ('sampler_schedule_stop', ctypes.c_float), ('train_schedule', ctypes.c_int32),
       ('train_schedule_start', ctypes.c_float), ('train_schedule_stop', ctypes.c_float),
       ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32),
-      ('attn_query_planes', ctypes.c_int32)]
+      ('attn_q_planes', ctypes.c_int32), ('attn_p_planes', ctypes.c_int32), ('graph_steps', ctypes.c_int32),
+      ('weight_prefetch', ctypes.c_int32)]
 
 
 _libs = {}
@@ -97,8 +99,10 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   if planes in _libs:
     return _libs[planes]
   LIB_PATH = LIB_PATHS[planes]
-  # same-box A/B of two builds (tools/ab_bench.sh): MSD_AMD_LIB=<path> replaces the half-plane library.  An older
-  # build may lack the newest entry points; those stay unbound (calling one raises AttributeError).
+  # same-box A/B of two builds (tools/ab_bench.sh, the experiments build of tools/ubench/exp): MSD_AMD_LIB=<path>
+  # replaces the half-plane library.  This is the ONLY environment variable the package reads; the library itself
+  # reads none.  An older build may lack the newest entry points: they stay unbound (calling one raises
+  # AttributeError) and a warning names them.
   override = os.environ.get('MSD_AMD_LIB') if planes == 'f16' else None
   if override:
     LIB_PATH = override
@@ -112,8 +116,17 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   except OSError as e:  # missing ROCm runtime etc.
     raise NativeLibraryError('cannot load %s: %s' % (LIB_PATH, e)) from e
   present = [sym for sym in EXPORTED_SYMBOLS if hasattr(lib, sym)]
-  if len(present) != len(EXPORTED_SYMBOLS) and not override:
-    raise NativeLibraryError('%s does not export %s' % (LIB_PATH, sorted(set(EXPORTED_SYMBOLS) - set(present))))
+  if len(present) != len(EXPORTED_SYMBOLS):
+    missing = sorted(set(EXPORTED_SYMBOLS) - set(present))
+    if not override:
+      raise NativeLibraryError('%s does not export %s' % (LIB_PATH, missing))
+    import warnings
+    warnings.warn('MSD_AMD_LIB=%s does not export %s: those entry points are unbound' % (LIB_PATH, missing), RuntimeWarning)
+  if override:
+    lib.msd_version.restype = ctypes.c_char_p
+    ver = lib.msd_version() or b''
+    if ('abi %d' % ABI_VERSION).encode() not in ver:
+      raise NativeLibraryError('MSD_AMD_LIB=%s is %r: this package binds ABI %d (msd_config layout)' % (LIB_PATH, ver, ABI_VERSION))
   c = ctypes
   vp, i32, i64, u64, u32 = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_uint32
   lib.msd_version.restype = c.c_char_p

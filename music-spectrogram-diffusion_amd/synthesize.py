@@ -31,9 +31,10 @@ def main(argv=None) -> int:
   ap.add_argument('--precision', choices=['f16x3', 'f16', 'bf16x3', 'bf16'], default='f16x3',
                   help="'f16x3' (default): hi + lo IEEE-half operand planes, float32-class; 'bf16x3': bfloat16 planes "
                        "(float32's exponent range, twice the rounding error); 'f16' / 'bf16': one plane, not parity-grade")
-  ap.add_argument('--range-fallback', action='store_true',
-                  help="switch to 'bf16x3' and repeat the segment if an activation leaves the half-plane range "
-                       "(native.RangeError) instead of failing")
+  ap.add_argument('--no-range-fallback', dest='range_fallback', action='store_false',
+                  help="fail with native.RangeError when an activation leaves the half-plane range (|x| > 65504) instead "
+                       "of switching to 'bf16x3' and repeating the segment (the default: a real checkpoint's residual "
+                       "stream may have outlier channels; the reference is float32 and never fails on them)")
   ap.add_argument('--out', default=None, help='.npy file for the mel frames [frames, 128]')
   ap.add_argument('--on-too-long', choices=['error', 'truncate'], default='error')
   ap.add_argument('--dry-run', action='store_true')

@@ -259,17 +259,12 @@ def test_empty_inputs_give_unconditional_result(tiny_ctx):
   helpers.assert_fp32_class(got, ref64, ref32, 'empty')
 
 
-@pytest.mark.parametrize('switch', [None, 'MSD_BIG_PAIR', 'MSD_BIG_WIDE', 'MSD_BIG_LS'])
-def test_batched_songs_use_big_tiles_and_match_oracle(switch, monkeypatch):
+def test_batched_songs_use_big_tiles_and_match_oracle():
   """16 songs per handle: M = 2*16*64 = 2048 rows -> the 128-row GEMM tiles of the batched
   path (msd_api.hip big_m_threshold).  emb 192 / 3 heads / mlp 256 make every N a multiple of the
   96/128-column tiles so all big instantiations run; checked per song against the oracle.
-  `switch`: the batched path's alternative tile kernels, off by default (built, parity-green, not
-  faster) -- K = 32 tiles with two blocks per CU (gemm_h16_pair.h, all five 128-row launches), the 256 x 128
-  eight-wave tile and the 256 x 128 tile with loader waves (gemm_h16_wide.h / gemm_h16_ls.h, gated-MLP input)."""
+  (The rejected alternative tiles of the experiments build run the same test: tests/test_gpu_experiments.py.)"""
   import dataclasses
-  if switch:
-    monkeypatch.setenv(switch, '1')   # read by msd_create
   base = msd_amd.config.preset('tiny_context', num_steps=4)
   spec = dataclasses.replace(base, t5=dataclasses.replace(base.t5, emb_dim=192, num_heads=3))
   params = msd_amd.synthetic.init_params(spec, 5, norm_scale_jitter=0.1)
@@ -373,78 +368,6 @@ def test_key_split_cross_attention_edge_lengths(valid):
       want = fm.decoder_pass(z.astype(np.float64), step, True)
       err = np.abs(eps.cpu().numpy() - want).max() / np.abs(want).max()
       assert err < 2e-4, (valid, mask, step, err)
-
-
-def test_xcd_resident_chain_kernel_matches_separate_launches(monkeypatch):
-  """MSD_CHAIN=1: MLP-in -> MLP-out -> next layer's QKV as ONE launch whose phases are separated by
-  XCD-local barriers (csrc/chain.h; off by default because it measured slower).  Same tiles, same arithmetic:
-  the eps of a decoder pass and a whole sampled segment must agree with the separate-launch path."""
-  import torch
-  spec = msd_amd.config.preset('tiny_context', num_steps=6)
-  params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
-  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
-  init_z, noise = helpers.make_noise(spec, batch=2)
-  outs, eps = {}, {}
-  for chain in ('0', '1'):
-    monkeypatch.setenv('MSD_CHAIN', chain)
-    model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
-    outs[chain], _ = model.predict(batch, init_z=init_z, noise=noise)
-    nm = model._get_native()
-    z = torch.as_tensor(init_z).cuda()
-    e = torch.zeros_like(z)
-    nm.decoder_pass(2, 3, z, True, e)
-    torch.cuda.synchronize()
-    eps[chain] = e.cpu().numpy()
-  rel = np.abs(eps['1'] - eps['0']).max() / np.abs(eps['0']).max()
-  print('chain vs separate launches: decoder pass max rel diff %.2e' % rel)
-  assert rel < 1e-5
-  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
-  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
-  helpers.assert_fp32_class(outs['1'], ref64, ref32, 'chain')
-
-
-@pytest.mark.parametrize('preset,mask', [('tiny_context', 'ragged'), ('tiny_context', 'zeros'), ('tiny', 'ones')])
-def test_hoisted_cross_query_projection_matches_the_plain_order(monkeypatch, preset, mask):
-  """MSD_HOIST_Q (default on): the cross-attention query projection runs in the launch of the self-attention
-  output projection, on [x0 (.) gamma | attention output] . [Wq ; Wo diag(gamma) Wq], and the RMSNorm's 1/rms is
-  applied to the logits inside the attention kernel (csrc/msd_api.hip decoder_layers).  Exact algebra, different
-  rounding order: single decoder passes must agree with the un-hoisted order far inside the float32 class, both
-  must sit on the float64 oracle, and a sampled segment stays in the float32 class."""
-  import torch
-  from oracle import backend, fast
-  spec = msd_amd.config.preset(preset, num_steps=6)
-  params = msd_amd.synthetic.init_params(spec, 11, norm_scale_jitter=0.3)
-  batch = helpers.make_batch(spec, batch=2, ctx_mask=mask) if spec.has_context else helpers.make_batch(spec, batch=2)
-  init_z, noise = helpers.make_noise(spec, batch=2)
-  cfg, dc = helpers.oracle_configs(spec)
-  xp = backend.TorchBackend('float64')
-  fm = fast.FastModel(xp, cfg, dc, params, spec.has_context)
-  if spec.has_context:
-    fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
-  else:
-    fm.encode(batch['encoder_input_tokens'])
-  outs, eps = {}, {}
-  for hoist in ('0', '1'):
-    monkeypatch.setenv('MSD_HOIST_Q', hoist)
-    model = msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ALL_PLANES)
-    outs[hoist], _ = model.predict(batch, init_z=init_z, noise=noise)
-    nm = model._get_native()
-    z = torch.as_tensor(init_z).cuda()
-    e = torch.zeros_like(z)
-    for step in (5, 0):
-      nm.decoder_pass(2, step, z, True, e)
-      torch.cuda.synchronize()
-      eps[hoist, step] = e.cpu().numpy().astype(np.float64)
-  for step in (5, 0):
-    ref = xp.to_numpy(fm.decoder_pass(xp.asarray(init_z), step, True)).astype(np.float64)
-    rel = np.abs(eps['1', step] - eps['0', step]).max() / np.abs(eps['0', step]).max()
-    e1 = np.abs(eps['1', step] - ref).max() / np.abs(ref).max()
-    e0 = np.abs(eps['0', step] - ref).max() / np.abs(ref).max()
-    print('%s/%s step %d: hoisted vs plain %.2e; vs float64 oracle: hoisted %.2e, plain %.2e' % (preset, mask, step, rel, e1, e0))
-    assert rel < 5e-5 and e1 < 2e-4 and e0 < 2e-4
-  ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
-  ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
-  helpers.assert_fp32_class(outs['1'], ref64, ref32, 'hoisted query projection')
 
 
 @pytest.mark.parametrize('preset,mask', [('tiny_context', 'ragged'), ('tiny_context', 'zeros'), ('tiny', 'ones')])

@@ -19,7 +19,7 @@ def test_prefetch_destination_registers_are_never_rewritten(tmp_path, defs):
   listing = str(tmp_path / 'msd.s')
   subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S'] + defs + ['-o', listing, src],
                  check=True, cwd=os.path.dirname(src), capture_output=True)
-  out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_prefetch_regs.py'), listing],
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'music-spectrogram-diffusion_amd', 'check_prefetch_regs.py'), listing],
                        capture_output=True, text=True)
   print(out.stdout[-400:])
   assert out.returncode == 0, out.stdout[-2000:]

@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_ls_kernel(GemmParams p, Epi e
   const int m0 = bm * BM, n0 = bn * BN;
   const int nk = p.K / kPairBK;   // >= NS (launcher)
 
+  MSD_TS_BEGIN(7, blockIdx.x)
   if (wave >= 4) {
     // ================================================ loader waves ===================================================
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -93,6 +94,9 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_ls_kernel(GemmParams p, Epi e
   }
 #pragma unroll
     for (int s = 0; s < NS; ++s) MSD_L_ISSUE(s, s)
+#if MSD_TIMESTAMPS
+    if (threadIdx.x == 256 && blockIdx.x < kTsBlocks) g_msd_ts[7][blockIdx.x][7] = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");   // tile 0 landed
     __builtin_amdgcn_s_barrier();                                          // B(-1): tile 0 visible
     int buf = 0;
@@ -140,6 +144,7 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_ls_kernel(GemmParams p, Epi e
         acc[i_][j_] = MSD_MFMA_16X16X32(fb[PB_][j_], fa[PA_][i_], acc[i_][j_], 0, 0, 0);                        \
   }
   __builtin_amdgcn_s_barrier();   // B(-1): tile 0 visible
+  MSD_TS_AT(7, blockIdx.x, 1)
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // hi planes first; when they are here (the lgkm counter is four bits wide: with all 24 reads outstanding the
@@ -166,10 +171,12 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_ls_kernel(GemmParams p, Epi e
   float* slab = reinterpret_cast<float*>(smem);
   char* const aux = smem + AUX_OFF;
   const int lm = lane & 15, ln = (lane >> 4) * 4;
+  MSD_TS_AT(7, blockIdx.x, 2)
   __syncthreads();   // every consumer is done with the ring (the loaders' last DMA landed before B(nk-2)): slab + aux
 #pragma unroll
   for (int q = 0; q < 4; ++q) epi.template prefetch<HM, BN, 0>(aux + q * p.aux_half, m0 + q * HM, n0, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MSD_TS_AT(7, blockIdx.x, 3)
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     __syncthreads();   // h = 0: aux rows visible; later: the previous pass's slab has been read
@@ -187,7 +194,10 @@ __global__ void __launch_bounds__(512, 2) gemm_h16_ls_kernel(GemmParams p, Epi e
     epi.template stats<HM, LDS_LD>(slab, m0 + h * HM, tid, auxq);
     __syncthreads();
     epi.template run<HM, BN, LDS_LD>(slab, m0 + h * HM, n0, tid, auxq, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+    if (h == 0) { MSD_TS_AT(7, blockIdx.x, 4) }
   }
+  MSD_TS_AT(7, blockIdx.x, 5)
+  MSD_TS_END(7, blockIdx.x, gridDim.x)
 }
 
 template <int NP, int BN>
