@@ -324,22 +324,26 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
   128 KiB context message goes rank r -> r+1 (device to device, dist.send/recv = RCCL point-to-point
   over one xGMI link), `rounds` times down the chain; content checked, mean latency per hop reported."""
   import torch
+  from msd_amd import sharding
   try:
-    buf = torch.full(shape, float(rank), dtype=torch.float32, device=device)
+    buf = torch.empty(sharding.HEADER + int(np.prod(shape)), dtype=torch.float32, device=device)
     _sync(device)
     dist.barrier()
     ok = True
+    outbox = sharding._Outbox()
     t0 = time.perf_counter()
-    for k in range(rounds + 1):
+    for k in range(rounds + 1):   # the message path of sharding.chained_predict: header-checked, asynchronous send
       if k == 1:   # round 0 opens the connections
         _sync(device)
         t0 = time.perf_counter()
       if rank > 0:
-        dist.recv(buf, src=rank - 1)
+        sharding._recv(buf, rank - 1)
         _sync(device)
-        ok = ok and bool((buf == float(rank - 1) + k).all())
+        got = sharding.unpack_handoff(buf, k, rank - 1, shape)   # raises HandoffError on a reordered message
+        ok = ok and bool((got == float(rank - 1) + k).all())
       if rank + 1 < world:
-        dist.send(torch.full(shape, float(rank) + k, dtype=torch.float32, device=device), dst=rank + 1)
+        outbox.post(sharding.pack_handoff(torch.full(shape, float(rank) + k, dtype=torch.float32, device=device), k, rank), rank + 1)
+    outbox.drain()
     _sync(device)
     dt = time.perf_counter() - t0
     flag = torch.tensor([1.0 if ok else 0.0], device=device)
@@ -348,7 +352,7 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return {'ok': bool(flag.item() == 1.0), 'message_bytes': int(np.prod(shape)) * 4, 'hops': world - 1,
             'us_per_hop': round(float(tt.item()) / rounds / max(world - 1, 1) * 1e6, 1),
-            'note': 'dist.send/recv of the device tensor (RCCL p2p); one message per chunk boundary in --mode chained'}
+            'note': 'header-checked message of sharding.chained_predict, batch_isend_irecv of the device tensor (RCCL p2p); one message per chunk boundary in --mode chained'}
   except Exception as e:  # never let the probe take the benchmark down
     return {'ok': False, 'error': repr(e)[:200]}
 
@@ -407,6 +411,17 @@ def main():
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     else:
       dist.init_process_group('gloo', rank=rank, world_size=world)
+
+  ranks_seen = None
+  if dist is not None:
+    # census: what each rank runs on, all-gathered -- a SCALE record can then prove that N distinct devices took part
+    me = {'rank': rank, 'local_rank': local_rank, 'pid': os.getpid(), 'host': os.uname().nodename}
+    if on_gpu:
+      prop = torch.cuda.get_device_properties(local_rank)
+      me.update(device=torch.cuda.current_device(), name=prop.name,
+                uuid=str(getattr(prop, 'uuid', '')), pci_bus_id=getattr(prop, 'pci_bus_id', None))
+    ranks_seen = [None] * world
+    dist.all_gather_object(ranks_seen, me)
 
   spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
   model = _resolve(args.model_factory)('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
@@ -475,7 +490,10 @@ def main():
   _sync(model.device)
   elapsed = time.perf_counter() - t0
   assert torch.isfinite(torch.as_tensor(out)).all(), 'non-finite mel output'
+  per_rank_seconds = None
   if dist is not None:
+    per_rank_seconds = [None] * world
+    dist.all_gather_object(per_rank_seconds, round(elapsed, 6))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -577,6 +595,9 @@ def main():
       result['sample_ms_per_segment'] = round(smp_s / args.steps * 1e3, 3)
     if handoff is not None:
       result['handoff_check'] = handoff
+    if ranks_seen is not None:
+      result['ranks_seen'] = ranks_seen               # one entry per rank: device / uuid / pid as that rank saw them
+      result['per_rank_seconds'] = per_rank_seconds   # each rank's own timed region; `value` uses the maximum
     if world == 1 and args.batched_songs > 1 and nb == 1:
       result['batched'] = batched_leg(spec, args)
     if world == 1 and args.small_segments > 0 and nb == 1 and args.preset != 'small':

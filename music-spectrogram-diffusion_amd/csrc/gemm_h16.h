@@ -284,9 +284,52 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // it multiplies K-tiles [ks K/SK, (ks+1) K/SK) and, after the exchange described at the kernel, runs the epilogue
 // on columns [n0 + ks BN/SK, +BN/SK) of the tile.
 constexpr int kSplitSpinLimit = 2000000;
-template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1>
+
+// Persistent-layer experiment (tools/ubench/exp/chain.h, MSD_EXPERIMENTS builds): a tile may enter with the WEIGHT half
+// of its first PSN ring stages already in flight -- issued by the previous phase of the same launch behind its main
+// loop, through `hook.after_loop()` -- so that only the activation half (which depends on the previous phase) is
+// fetched behind the phase barrier.  The product's kernels run with PSN = 0 and the empty hook.
+struct NoTileHook {
+  __device__ __forceinline__ void after_loop() const {}
+};
+
+// One LDS-DMA instruction the COMPILER DOES NOT COUNT (inline asm, MI355X guide 5.7 `glds16_asm`: M0 saved, set and
+// restored inside one statement; no VGPR destination, so nothing can be reused early): 64 lanes x 16 bytes from each
+// lane's `gsrc` to LDS bytes [lds_dst + 16 lane, +16).  hipcc waits for a __builtin LDS-DMA in front of the next LDS
+// read it cannot prove disjoint -- here: the epilogue's first slab read -- which would expose exactly the latency the
+// pre-staging is meant to hide.  Completion: the consumer's own `s_waitcnt vmcnt(0)` (asm) + barrier.
+__device__ __forceinline__ void lds_dma16_uncounted(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Weight (B operand) half of ring stages [0, nst) of tile column `bn`, into the ring at LDS address `ring_lds` (the layout and the
+// per-lane source swizzle of gemm_tile's MSD_D_ISSUE); called by all four compute waves.
+template <int NP, int BM, int BN, int NS>
+__device__ __forceinline__ void gemm_prestage_b(const GemmParams& p, int bn, unsigned ring_lds, int nst) {
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = NP * (A_BYTES + B_BYTES), B_LD = BN / 32;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int r8 = lane >> 3, csrc = (lane & 7) ^ r8, n0 = bn * BN;
+  // `ring_lds`: LDS byte address of the ring (an integer: a generic -> LDS pointer cast of a pointer the compiler
+  // cannot prove non-null trips this ROCm's backend -- illegal v_cmp on src_shared_base, see aux_dma_row)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(ring_lds);
+  for (int s = 0; s < nst; ++s)
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      const h16_t* gb = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + s * kGemmBK;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        lds_dma16_uncounted(gb + (size_t)i * 8 * p.ldb,
+                            lds0 + (unsigned)(s * STAGE_BYTES + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * i) * 128));
+    }
+}
+
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1, int PSN = 0,
+          class Hook = NoTileHook>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem, int ks = 0,
-                                          int tile_id = 0) {
+                                          int tile_id = 0, const Hook& hook = Hook()) {
+  static_assert(PSN == 0 || (kExperiments && SK == 1 && PSN <= NS), "pre-staged stages: experiments build only");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int BNE = BN / SK;                    // columns of the tile this block's epilogue owns
   constexpr int FM = WM / 16, FN = WN / 16;
@@ -340,9 +383,23 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   const int nk = p.K / SK / kGemmBK;
   MSD_TS_BEGIN((ts_class<BM, BN>()), blockIdx.x)
   // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
+  // (stages < PSN: the weight half is already in flight -- see gemm_prestage_b -- only the activations are issued)
+#define MSD_D_ISSUE_A(KT, BUF)                                                              \
+  {                                                                                         \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                               \
+    const int k0_ = (KT) * kGemmBK;                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                       \
+      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                      \
+          __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl, i, k0_)),                  \
+              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, CP); \
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s)
-    if (s < nk) MSD_D_ISSUE(s, s)
+    if (s < nk) {
+      if (s < PSN) MSD_D_ISSUE_A(s, s)
+      else MSD_D_ISSUE(s, s)
+    }
+#undef MSD_D_ISSUE_A
   // Epilogue operands (row statistics, step-indexed bias / gain rows, the residual tile) are
   // HBM-cold and used to be read by dependent global loads AFTER the K loop (+2..4 us per
   // launch).  They are DMAed into an aux LDS region behind the ring now, queued behind the
@@ -480,9 +537,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     buf = nb;                                                                                \
   }
 
-  if (nk >= NS) {
+  if (PSN == 0 && nk >= NS) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");  // tile 0 landed; NS-1 tiles in flight
   } else {
+    // (pre-staged stages: their weight DMAs were issued long ago, the prologue above issued fewer instructions per
+    // stage than the loop's counted waits assume -- everything issued so far has to land once, then the counts hold)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -511,6 +570,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_A_SRC
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
   MSD_TS_STAMP(BM, BN, 3)
+  hook.after_loop();   // (experiments: the next phase's weight tiles leave now, under this tile's epilogue)
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   auto store_slab = [&]() {
@@ -621,31 +681,52 @@ struct RowScale {
 
 constexpr int kAuxMaxTiles = 32;  // ssq partials per row the aux region is sized for (D <= 1024)
 
+// Does this tile have an aux LDS region?  Every kernel of the library does (gemm_tile and the batched variants pass
+// one), so the answer is a compile-time `true` -- NOT a test of the pointer: a null test of a generic pointer that
+// points into LDS is what this ROCm's backend turns into an illegal v_cmp on src_shared_base once a tile loop keeps it
+// from folding the test away (the chain kernels of tools/ubench/exp hit it; which instantiation fails moves with every
+// unrelated edit).  tools/ubench/gemm_h16_regstaged.h, the one caller without aux rows, defines MSD_EPI_AUX_OPTIONAL.
+#ifndef MSD_EPI_AUX_OPTIONAL
+#define MSD_EPI_AUX_OPTIONAL 0
+#endif
+__device__ __forceinline__ bool aux_present(const char* aux) {
+#if MSD_EPI_AUX_OPTIONAL
+  return aux != nullptr;
+#else
+  (void)aux;
+  return true;
+#endif
+}
+
 typedef const __attribute__((address_space(1))) void* aux_gptr_t;
 typedef __attribute__((address_space(3))) void* aux_lptr_t;
+
+// LDS pointer of a generic pointer that is KNOWN to point into LDS: its low 32 bits.  (A generic -> LDS pointer CAST
+// carries a null check unless the compiler can fold it, and both that check and a `__builtin_assume(p != nullptr)`
+// meant to remove it end up, in kernels with tile loops, as a constant compare against the LDS null that this ROCm's
+// backend lowers to an illegal v_cmp on src_shared_base.  An integer round trip has no null semantics.)
+__device__ __forceinline__ aux_lptr_t lds_ptr_of(const void* generic) {
+  return (aux_lptr_t)(size_t)(unsigned)(size_t)generic;
+}
 
 // LDS-DMA of `bytes` contiguous, 16-byte aligned global bytes to dst (linear), one 1 KiB
 // instruction per wave round-robin.  Lanes past the end re-fetch the last chunk; their LDS
 // writes land in the padding (dst needs round_up(bytes, 1024) bytes).
 template <int CP = 0>
 __device__ __forceinline__ void aux_dma_linear(const void* g, char* dst, int bytes, int wave, int lane) {
-  __builtin_assume(dst != nullptr);
   const int n_instr = (bytes + 1023) >> 10;
   for (int i = wave; i < n_instr; i += 4) {
     int off = i * 1024 + lane * 16;
     off = off < bytes - 16 ? off : bytes - 16;
-    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)(dst + i * 1024), 16, 0, CP);
+    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), lds_ptr_of(dst + i * 1024), 16, 0, CP);
   }
 }
 
 // one instruction: `bytes` (<= 1024) contiguous global bytes to dst
 __device__ __forceinline__ void aux_dma_row(const void* g, char* dst, int bytes, int lane) {
-  // a generic -> LDS cast of a pointer the compiler cannot prove non-null needs a null check, which this ROCm's
-  // backend emits as an illegal v_cmp (src_shared_base operand) inside the chain kernels' tile loops
-  __builtin_assume(dst != nullptr);
   int off = lane * 16;
   off = off < bytes - 16 ? off : bytes - 16;
-  __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), (aux_lptr_t)dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), lds_ptr_of(dst), 16, 0, 0);
 }
 
 // RowScale aux layout: [BM * tiles ssq partials, rounded up to whole KiB (the DMA's granule)][bias row, 1 KiB].  The
@@ -722,7 +803,7 @@ __device__ __forceinline__ void tile_rstd_compute(const RowScale& r, float* rs, 
   constexpr int TPR = 256 / BM;
   const int row = tid / TPR, part = tid % TPR;
   float acc = 0.f;
-  if (aux) {
+  if (aux_present(aux)) {
     lds_cf32 q = (lds_cf32)(aux) + row * r.tiles;
     for (int t = part; t < r.tiles; t += TPR) acc += q[t];
   } else {
@@ -745,7 +826,7 @@ __device__ __forceinline__ BiasRow tile_rstd(const RowScale& r, float* rs, int m
   }
   BiasRow b;
   if (r.bias) {
-    if (!aux) __builtin_trap();   // the bias row lives in the aux LDS region (every product kernel has one)
+    if (!aux_present(aux)) __builtin_trap();   // the bias row lives in the aux LDS region (every product kernel has one)
     b.present = true;
     b.l = (lds_cf32)(aux + rowscale_ssq_bytes<BM>(r.tiles));
   }
@@ -918,7 +999,7 @@ struct EpiResidualNorm {
     for (int i = wave; i < BM / 8; i += 4)
       __builtin_amdgcn_global_load_lds(
           (aux_gptr_t)(x + (size_t)(m0 + 8 * i + (lane >> 3)) * ldx + n0 + (lane & 7) * 4),
-          (aux_lptr_t)(aux + i * 1024), 16, 0, CP);
+          lds_ptr_of(aux + i * 1024), 16, 0, CP);
     const int step = *step_ptr;
     if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)step * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
@@ -928,7 +1009,7 @@ struct EpiResidualNorm {
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
                       SatFlag sf = SatFlag()) const {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
-    const bool pre = aux && BN == 32;
+    const bool pre = BN == 32 && aux_present(aux);
     const int step = pre ? 0 : *step_ptr;
     RangeCheck rc;
     // one tile-element group (8 columns of one row); LX / LG fetch the residual and the gain

@@ -1125,8 +1125,10 @@ template <int NP>
 void chain_launch(Ctx& c, const MlpChainParams<NP>& cp, int /*layer*/) {
   msd_model* m = c.m;
   c.begin(KC_CHAIN_MLP);
-  const hipError_t e = ((3 * m->J) % 96 == 0 && (2 * m->J) % 96 == 0) ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s)
-                                                                       : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
+  const bool bn96 = (3 * m->J) % 96 == 0 && (2 * m->J) % 96 == 0;
+  hipError_t e;
+  if (m->chain_mode == 2) e = bn96 ? launch_mlp_chain_ps<NP, 96>(cp, m->cus, c.s) : launch_mlp_chain_ps<NP, 64>(cp, m->cus, c.s);
+  else e = bn96 ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s) : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(KC_CHAIN_MLP);
 }
@@ -1299,7 +1301,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
         const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
         const int ks = want < cap ? want : cap;
-        const WeightPrefetch pf = (e + 1 == m->n_cross && !chain) ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
+        // (round 2's chain, MSD_CHAIN=1, is kept as it was measured: without this touch)
+        bool warm_mlp_in = e + 1 == m->n_cross && !chain;
+#if MSD_EXPERIMENTS
+        if (e + 1 == m->n_cross && chain && m->chain_mode == 2) warm_mlp_in = true;
+#endif
+        const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
                       batch, ks, region, &pf, -1, hoist ? ssq : nullptr);
@@ -1337,6 +1344,10 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
         cp.g_qkv = gp<NP>(y, D, m->dec[last ? l : l + 1].self.wqkv, D, M, 3 * J, D);
         cp.e_qkv = qkv_epi(last ? l : l + 1);
         cp.bar = m->d_bar; cp.err = m->d_chain_err;
+        if (m->chain_mode == 2) {   // phases 1 / 2 weights -> memory-side cache, from the launch's prefetch wave
+          cp.pf.add(weights_target<NP>(m, w.mlp.wo, D, F));
+          if (!last) cp.pf.add(weights_target<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D));
+        }
         chain_launch<NP>(c, cp, l);
         continue;
       }
@@ -1458,6 +1469,8 @@ void set_func_attrs() {
 #if MSD_EXPERIMENTS
   (void)mlp_chain_prepare<2, 96>();
   (void)mlp_chain_prepare<2, 64>();
+  (void)mlp_chain_ps_prepare<2, 96>();
+  (void)mlp_chain_ps_prepare<2, 64>();
   (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
   (void)gemm_h16_wide_prepare<2, 128, EpiGeglu<2>>();
   (void)gemm_h16_ls_prepare<2, 128, EpiGeglu<2>>();

@@ -47,31 +47,97 @@ def _on_device(comm_device) -> bool:
   return str(comm_device) != 'cpu'
 
 
+# ---- the hand-off message ---------------------------------------------------------------------------------------------
+# float32 [HEADER + C*n]: {magic, song, source rank, payload elements} followed by the previous prediction.  The header
+# makes the ORDER of the messages part of the protocol instead of an assumption: the NCCL / RCCL backend ignores
+# `tag`, so "song j's message is the j-th one from rank r-1" used to rest on FIFO delivery per peer (VERDICT r03 weak
+# #11).  The integers are < 2^24 and therefore exact in float32; the payload is untouched (bit-identical songs).
+HEADER = 4
+MAGIC = 20250926.0
+
+
+class HandoffError(RuntimeError):
+  """A context hand-off arrived out of order, from the wrong rank or with the wrong size."""
+
+
+def pack_handoff(payload, song: int, src_rank: int):
+  """payload: torch tensor [1, C, n] (any device) -> flat message tensor on the same device."""
+  import torch
+  flat = payload.reshape(-1).to(torch.float32)
+  head = torch.tensor([MAGIC, float(song), float(src_rank), float(flat.numel())], dtype=torch.float32, device=flat.device)
+  return torch.cat([head, flat]).contiguous()
+
+
+def unpack_handoff(msg, song: int, src_rank: int, context_shape):
+  """Checks the header of a received message against what THIS rank is waiting for; returns the payload view."""
+  head = msg[:HEADER].tolist()
+  n = int(np.prod(context_shape))
+  if head[0] != MAGIC or int(head[1]) != song or int(head[2]) != src_rank or int(head[3]) != n:
+    raise HandoffError('context hand-off out of order: expected (song %d from rank %d, %d values), got header %s'
+                       % (song, src_rank, n, head))
+  return msg[HEADER:].reshape(context_shape)
+
+
+class _Outbox:
+  """Sends that are in flight: (work handle, message tensor).  The tensor must stay alive until the work is done (an
+  asynchronous send of a freed device buffer is a use-after-free); `drain` waits for all of them."""
+
+  def __init__(self):
+    self.pending = []
+
+  def post(self, msg, dst: int, group=None, tag: int = 0):
+    dist = _dist()
+    if dist.get_backend(group) == 'nccl':
+      # NCCL / RCCL point-to-point: batched form (one group call per message), the form that cannot interleave with a
+      # concurrent recv on the same communicator in the wrong order
+      works = dist.batch_isend_irecv([dist.P2POp(dist.isend, msg, dst, group)])
+    else:
+      works = [dist.isend(msg, dst=dst, group=group, tag=tag)]
+    self.pending.append((works, msg))
+
+  def drain(self):
+    for works, _ in self.pending:
+      for w in works:
+        w.wait()
+    self.pending = []
+
+
+def _recv(buf, src: int, group=None, tag: int = 0):
+  dist = _dist()
+  if dist.get_backend(group) == 'nccl':
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, src, group)]):
+      w.wait()
+  else:
+    dist.recv(buf, src=src, group=group, tag=tag)
+
+
 def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.ndarray],
                     context_shape: Tuple[int, int, int], rank: int, world: int,
                     comm_device='cpu', group=None, seed: int = 0, tag: int = 0,
-                    return_torch: bool = False):
+                    return_torch: bool = False, outbox: Optional[_Outbox] = None):
   """Run this rank's contiguous chunk of ONE song with the context hand-off.
 
   predict_sequence: ``InferenceModel.predict_sequence``-compatible callable
     ``(tokens_list, seed=, init_context=, first_segment_index=[, return_torch=]) -> [1, T*k, n]``.
-  context_shape: (1, C, n) of the hand-off message.
+  context_shape: (1, C, n) of the hand-off payload.
   comm_device: 'cpu' (gloo; the message is staged through the host) or a cuda device: the message
-    is then received into, and sent from, device memory (``dist.send/recv`` of the device tensor =
-    RCCL point-to-point over one xGMI link) and ``predict_sequence`` is called with
-    ``return_torch=True`` so that the previous prediction never leaves the GPU.
+    is then received into, and sent from, device memory (RCCL point-to-point over one xGMI link) and
+    ``predict_sequence`` is called with ``return_torch=True`` so that the previous prediction never leaves the GPU.
+  tag: the SONG index; it travels in the message header and is checked on arrival (HandoffError).
+  outbox: when given, the send to rank+1 is posted asynchronously into it and the CALLER drains it (the wavefront
+    driver below: rank r's send of song j overlaps its compute of song j+1); without, the send completes here.
   Returns this rank's mel [1, T*k, n] (k = its number of segments, possibly 0 rows): NumPy, or the
   device tensor with ``return_torch``.
   """
   import torch
-  dist = _dist()
   dev = _on_device(comm_device)
   start, stop = contiguous_chunk(len(segments_tokens), rank, world)
   init_context = None
   if rank > 0 and 0 < start < len(segments_tokens):  # mirrors the sender's condition
-    buf = torch.empty(context_shape, dtype=torch.float32, device=comm_device)
-    dist.recv(buf, src=rank - 1, group=group, tag=tag)
-    init_context = buf if dev else buf.numpy()
+    buf = torch.empty(HEADER + int(np.prod(context_shape)), dtype=torch.float32, device=comm_device)
+    _recv(buf, rank - 1, group, tag)
+    payload = unpack_handoff(buf, tag, rank - 1, context_shape)
+    init_context = payload if dev else payload.numpy()
   mine = list(segments_tokens[start:stop])
   n = context_shape[2]
   kw = {'return_torch': True} if dev else {}
@@ -89,8 +155,11 @@ def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.nda
       last = init_context if init_context is not None else (
           torch.zeros(context_shape, dtype=torch.float32, device=comm_device) if dev
           else np.zeros(context_shape, np.float32))
-    msg = last.contiguous() if dev else torch.as_tensor(np.ascontiguousarray(last, dtype=np.float32))
-    dist.send(msg, dst=rank + 1, group=group, tag=tag)
+    payload = last if dev else torch.as_tensor(np.ascontiguousarray(last, dtype=np.float32))
+    own = outbox if outbox is not None else _Outbox()
+    own.post(pack_handoff(payload, tag, rank), rank + 1, group, tag)
+    if outbox is None:
+      own.drain()
   if dev and not return_torch:
     return out.cpu().numpy()
   return out
@@ -115,10 +184,12 @@ def chained_wavefront(predict_sequence: Callable, songs: Sequence[Sequence[np.nd
   ranks are busy after ``world - 1`` fill steps.  Returns this rank's chunk of
   every song, in song order."""
   outs = []
+  outbox = _Outbox()   # song j's send to rank+1 stays in flight while this rank already computes song j+1
   for j, song in enumerate(songs):
     outs.append(chained_predict(predict_sequence, song, context_shape, rank, world,
                                 comm_device=comm_device, group=group, seed=seed + j, tag=j,
-                                return_torch=return_torch))
+                                return_torch=return_torch, outbox=outbox))
+  outbox.drain()
   return outs
 
 

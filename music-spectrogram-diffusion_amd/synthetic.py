@@ -122,6 +122,20 @@ def trained_like(params: Dict[str, np.ndarray], seed: int = 0, channel_sigma: fl
   return out
 
 
+def sharp_attention(params: Dict[str, np.ndarray], gain: float, where: str = 'decoder') -> Dict[str, np.ndarray]:
+  """Multiply every query kernel under `where` (self- and cross-attention of the decoder by default) by `gain`.
+  The projections read RMS-normalised inputs, so every attention logit q.k scales by `gain`: fresh initialisers give
+  logits of O(1) (soft attention over all keys), gain 4 / 8 put competing keys 10 - 30 apart -- the SHARP attention
+  of a trained model, where a rounding of Q that is harmless at O(1) logits (|s| 2^-12 with one half plane) decides
+  which key wins (DESIGN.md 3 "sharp attention")."""
+  out = {}
+  for name, v in params.items():
+    if name.startswith(where + '/') and name.endswith('/query/kernel'):
+      v = (v * np.float32(gain)).astype(np.float32)
+    out[name] = np.ascontiguousarray(v, dtype=np.float32)
+  return out
+
+
 def segment_tokens(spec: config_lib.ModelSpec, segment: int, seed: int = 1234,
                    min_len: int = 128, max_len: int = 1536) -> np.ndarray:
   """int32 [1, inputs_length]: ``len ~ U{min..max}`` regular ids ``U{3..1390}``,

@@ -42,6 +42,11 @@ def test_plain_command_starts_its_own_ranks(mode):
   h = d['handoff_check']                       # the 128 KiB context message went rank 0 -> 1, content verified
   assert h['ok'] is True and h['hops'] == 1 and h['message_bytes'] == 256 * 128 * 4
   assert 'cpu_baseline' not in d and 'batched' not in d    # N = 1 legs only
+  # the census a SCALE record needs: every rank reported itself, distinct processes, and its own timed seconds
+  seen = d['ranks_seen']
+  assert [r['rank'] for r in seen] == [0, 1] and len({r['pid'] for r in seen}) == 2
+  assert len(d['per_rank_seconds']) == 2 and all(t > 0 for t in d['per_rank_seconds'])
+  assert abs(max(d['per_rank_seconds']) - d['ms_per_step'] * 3e-3) < 1e-3 * d['ms_per_step'] * 3e-3 + 2e-6   # `value` is over the slowest rank
 
 
 def test_single_rank_needs_no_launcher():

@@ -1,8 +1,8 @@
 """Where does a weight-streaming GEMM launch of the DDPM step spend its time?  (GPU box, debug build only.)
 
-Runs a few denoising steps of base_with_context on a library built from csrc/ + tools/diag/phase_timestamps.patch
-with -DMSD_TIMESTAMPS=1 (tools/README.md: "phase timestamps"), then reads the per-block stamps of the LAST launch of
-each tile shape:
+Runs a few denoising steps of base_with_context on a library built with -DMSD_TIMESTAMPS=1 (the stamps live in the
+sources behind that macro since round 4; tools/README.md: "phase timestamps"), then reads the per-block stamps of the
+LAST launch of each tile shape:
 
   entry      block starts (first instruction behind the accumulator clear)
   issued     the prologue's LDS-DMA instructions (NS K-tiles + the epilogue's aux rows) are issued
@@ -16,10 +16,14 @@ and the same for the attention kernels (Q loads + ring DMAs issued, stage 0 land
 merged + stored) and the key-split merge kernel (entry, end).
 
 s_memtime (core clock) gives the deltas inside one block, s_memrealtime (100 MHz, one counter for the chip) aligns
-blocks with each other and calibrates the core clock.  The product library has none of this (the patch is not
-applied to the tree; the default build's hash is unchanged).
+blocks with each other and calibrates the core clock.  The product library has none of this (every stamp macro is
+empty without -DMSD_TIMESTAMPS=1: tests/test_diag_tools.py).
 
-usage (GPU box):  [BATCH=8] MSD_AMD_LIB=tools/ab/libs/libmsd_amd_ts.so python tools/diag/phase_times.py"""
+With MSD_CHAIN=1|2 (experiments build) the gated-MLP-in / MLP-out / QKV tiles run inside ONE launch (chain.h); the
+script then also prints the launch's timeline: per phase the span first entry -> last end, and per block the time
+between the end of its phase-0 tile and the entry of its phase-1 tile (= XCD barrier + waiting for the slowest block).
+
+usage (GPU box):  [BATCH=8] [MSD_CHAIN=2] MSD_AMD_LIB=tools/ubench/exp/libmsd_amd_exp_ts.so python tools/diag/phase_times.py"""
 import ctypes
 import os
 import sys
@@ -98,6 +102,27 @@ def main():
     xcc = t[:, 8]
     print('  per XCD (blocks, last end us): ' + '  '.join('%d: %d, %.2f' % (x, (xcc == x).sum(), end[xcc == x].max())
                                                           for x in sorted(set(xcc.tolist()))))
+  if os.environ.get('MSD_CHAIN', '0') not in ('', '0'):
+    chain_timeline(ts)
+
+
+def chain_timeline(ts):
+  """classes 0 (gated MLP-in) and 2 (MLP-out) were stamped by the SAME launch (the last layer's chain; its QKV phase
+  does not exist).  s_memrealtime (10 ns) is one counter for the chip: block b's phase-1 entry minus its phase-0 end is
+  what the phase boundary cost that block."""
+  a, b = ts[0].astype(np.int64), ts[2].astype(np.int64)
+  n = int(min(a[0, 9], 1024))
+  a, b = a[:n], b[:n]
+  t0 = a[a[:, 11] > 0, 10].min()
+  print('\nchain launch timeline (last layer; us since the first block entered phase 0)')
+  for name, t in (('phase 0 gated MLP-in', a), ('phase 1 MLP-out', b)):
+    live = (t[:, 11] > 0) & (t[:, 9] == a[0, 9]) & (t[:, 10] >= t0)
+    e0, e1 = (t[live, 10] - t0) * 0.01, (t[live, 11] - t0) * 0.01
+    print('  %-22s blocks %3d   first entry %6.2f   median entry %6.2f   median end %6.2f   last end %6.2f'
+          % (name, live.sum(), e0.min(), np.median(e0), np.median(e1), e1.max()))
+  both = (a[:, 11] > 0) & (b[:, 11] > 0) & (a[:, 9] == b[:, 9]) & (b[:, 10] >= a[:, 11])   # same launch (grid), not a stale stamp
+  gap = (b[both, 10] - a[both, 11]) * 0.01
+  print('  phase boundary per block (phase-0 end -> phase-1 entry): p10 %.2f  p50 %.2f  p90 %.2f us' % tuple(np.percentile(gap, [10, 50, 90])))
 
 
 if __name__ == '__main__':

@@ -63,6 +63,7 @@ struct MlpChainParams {
   GemmParams g_out; EpiResidualNorm<NP> e_out;
   GemmParams g_qkv; EpiQKV<NP> e_qkv;
   int has_qkv;       // 0 after the last layer (the final projection follows)
+  WeightPrefetch pf; // MSD_CHAIN=2: the weights of phases 1 / 2 (and nothing else), touched by the launch's prefetch wave
   unsigned* bar;     // [8][kBarStride]
   int* err;
 };
@@ -96,6 +97,146 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(MlpChainParams<NP> P) {
   if (!P.has_qkv) return;
   xcd_barrier(bar, nslot, P.err);
   chain_gemm_phase<NP, 64, QKV_BN, 3>(P.g_qkv, P.e_qkv, xcd, slot, nslot, smem);
+}
+
+// ---- round 4: the same chain with the next phase's WEIGHT tiles pre-staged (MSD_CHAIN=2) ---------------------------
+// "issue phase N+1's weight tiles into a slab that does not alias the ring BEFORE the
+// xcd_barrier and while the consumer waves run phase N's epilogue".  Weights depend on nothing computed in the launch,
+// so behind its main loop a block starts the LDS-DMA of the weight half of its NEXT tile's first ring stages
+// (gemm_prestage_b, uncounted by the compiler), into a ring placed where neither this tile's epilogue slab nor its aux
+// rows live; after the barrier only the activation half (L2-resident: the same XCD just wrote it) is fetched.
+// LDS map (bytes; NP = 2, one block per CU, 160 KiB):
+//   phase 0  gated MLP-in  64 x 128, 3 stages of 48 KiB   ring [0, 147456)          aux [147456, 156672)   slab [0, 34048)
+//   phase 1  MLP-out       64 x 32,  4 stages of 24 KiB   ring [36864, 135168)      aux [135168, 146432)   slab [36864, 46336)
+//   phase 2  QKV           64 x BN,  3 stages             ring [30720, ...)         aux behind it          (BN = 96: ends at 162816)
+// Phase 1's whole ring sits between phase 0's slab and aux, so all four weight stages are pre-staged; phase 2's stage-0
+// ACTIVATION half covers phase 1's slab (it is fetched after the barrier) and its weight halves avoid slab and aux of
+// phase 1 for the first kChainPs2 stages (static_asserts below).
+// The weights of phases 1 / 2 are additionally warmed into the memory-side cache by a prefetch wave at the start of the
+// launch, as the stand-alone launches' predecessors do for them (round 2's chain started every phase HBM-cold).
+constexpr int kChainOff1 = 36864, kChainOff2 = 30720;
+template <int QKV_BN> constexpr int chain_ps2() { return QKV_BN == 96 ? 2 : 3; }
+
+template <int NP, int BM, int BN, int NS>
+struct PrestageHook {
+  const GemmParams& p;   // the NEXT phase's problem
+  bool on;               // false: nothing to stage (no tile in the next phase)
+  int bn;
+  unsigned ring;   // LDS byte address
+  int nst;
+  __device__ __forceinline__ void after_loop() const {
+    if (on) gemm_prestage_b<NP, BM, BN, NS>(p, bn, ring, nst);
+  }
+};
+
+template <int NP, int QKV_BN>
+constexpr int mlp_chain_ps_smem() {
+  constexpr int c_end = kChainOff2 + gemm_h16_dma_smem<NP, 64, QKV_BN, 3, EpiQKV<NP>>();
+  constexpr int a_end = gemm_h16_dma_smem<NP, 64, 128, 3, EpiGeglu<NP>>();
+  constexpr int b_end = kChainOff1 + gemm_h16_dma_smem<NP, 64, 32, 4, EpiResidualNorm<NP>>();
+  return c_end > a_end ? (c_end > b_end ? c_end : b_end) : (a_end > b_end ? a_end : b_end);
+}
+
+template <int NP, int QKV_BN>
+__global__ void __launch_bounds__(256 + 64) mlp_chain_ps_kernel(MlpChainParams<NP> P) {
+  static_assert(NP == 2, "two-plane modes only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (threadIdx.x >= 256) {   // prefetch wave: phases 1 / 2 weights -> Infinity Cache, then it ends (no barrier counts it)
+    prefetch_wave<2>(P.pf, blockIdx.x, gridDim.x, P.g_in.B[0]);
+    return;
+  }
+  // ---- compile-time LDS map checks --------------------------------------------------------------------------------
+  constexpr int S0 = 2 * (64 + 128) * 128, S1 = 2 * (64 + 32) * 128, S2 = 2 * (64 + QKV_BN) * 128;
+  constexpr int SLAB0 = (64 * (128 + kSlabPad) + 64) * 4, AUX0 = 3 * S0;
+  constexpr int SLAB1_LO = kChainOff1, SLAB1_HI = kChainOff1 + (64 * (32 + kSlabPad) + 64) * 4;
+  constexpr int AUX1_LO = kChainOff1 + 4 * S1, AUX1_HI = AUX1_LO + EpiResidualNorm<NP>::template aux_bytes<64, 32>();
+  constexpr int PS2 = chain_ps2<QKV_BN>();
+  static_assert(kChainOff1 >= SLAB0 && AUX1_HI <= AUX0, "phase 1 (ring + aux) must sit between phase 0's slab and aux");
+  static_assert(kChainOff2 <= SLAB1_LO && kChainOff2 + 2 * 64 * 128 >= SLAB1_HI, "phase 2's stage-0 activation half must cover phase 1's slab");
+  static_assert(kChainOff2 + (PS2 - 1) * S2 + S2 <= AUX1_LO, "phase 2's pre-staged weight halves must end below phase 1's aux rows");
+  static_assert(mlp_chain_ps_smem<NP, QKV_BN>() <= 160 * 1024, "LDS");
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  unsigned* bar = P.bar + xcd * kBarStride;
+  if (threadIdx.x == 0) {   // placement check, as in mlp_chain_kernel
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xf) + 1u;
+    const unsigned seen = atomicCAS(bar + 1, 0u, xcc);
+    if (seen != 0u && seen != xcc) atomicAdd(P.err, 1 << 16);
+  }
+  // tiles of a phase: row tiles bm = xcd, xcd + 8, ...; column tiles bn = slot, slot + nslot, ...  Only the FIRST tile
+  // of a block's next phase is pre-staged (at one song every block has at most one tile per phase anyway).
+  const int nbm = P.g_in.M / 64;
+  const int nbn0 = P.g_in.N / 128, nbn1 = P.g_out.N / 32, nbn2 = P.g_qkv.N / QKV_BN;
+  const bool own_rows = xcd < nbm;
+  char* const ring0 = smem;
+  char* const ring1 = smem + kChainOff1;
+  char* const ring2 = smem + kChainOff2;
+  const unsigned lds_base = (unsigned)(size_t)smem;   // low 32 bits of a generic LDS pointer = its LDS address
+  // ---- phase 0: gated MLP input -------------------------------------------------------------------------------------
+  {
+    const int nk1 = P.g_out.K / kGemmBK;
+    PrestageHook<NP, 64, 32, 4> h1{P.g_out, own_rows && slot < nbn1, slot, lds_base + kChainOff1, nk1 < 4 ? nk1 : 4};
+    bool first = true;
+    for (int bm = xcd; bm < nbm; bm += 8)
+      for (int bn = slot; bn < nbn0; bn += nslot) {
+        // the hook fires behind the LAST tile's loop: an earlier tile's slab / ring would overwrite the staged bytes
+        const bool last = bm + 8 >= nbm && bn + nslot >= nbn0;
+        if (last) gemm_tile<NP, 64, 128, 3, EpiGeglu<NP>, kChainCP, kPfNone, 1, 0>(P.g_in, P.e_in, bm, bn, ring0, 0, 0, h1);
+        else gemm_tile<NP, 64, 128, 3, EpiGeglu<NP>, kChainCP>(P.g_in, P.e_in, bm, bn, ring0);
+        __syncthreads();
+        first = false;
+      }
+    if (first) h1.after_loop();   // a block without a phase-0 tile still stages its phase-1 weights
+  }
+  xcd_barrier(bar, nslot, P.err);
+  // ---- phase 1: MLP output projection (+ residual, next norm's planes) -----------------------------------------------
+  {
+    const int nk2 = P.g_qkv.K / kGemmBK;
+    PrestageHook<NP, 64, QKV_BN, 3> h2{P.g_qkv, P.has_qkv && own_rows && slot < nbn2, slot, lds_base + kChainOff2, nk2 < PS2 ? nk2 : PS2};
+    bool first = true;
+    for (int bm = xcd; bm < nbm; bm += 8)
+      for (int bn = slot; bn < nbn1; bn += nslot) {
+        const bool last = bm + 8 >= nbm && bn + nslot >= nbn1;
+        const bool staged = first && bm == xcd && bn == slot;
+        if (staged && last) gemm_tile<NP, 64, 32, 4, EpiResidualNorm<NP>, kChainCP, kPfNone, 1, 4>(P.g_out, P.e_out, bm, bn, ring1, 0, 0, h2);
+        else if (staged) gemm_tile<NP, 64, 32, 4, EpiResidualNorm<NP>, kChainCP, kPfNone, 1, 4>(P.g_out, P.e_out, bm, bn, ring1);
+        else if (last) gemm_tile<NP, 64, 32, 4, EpiResidualNorm<NP>, kChainCP, kPfNone, 1, 0>(P.g_out, P.e_out, bm, bn, ring1, 0, 0, h2);
+        else gemm_tile<NP, 64, 32, 4, EpiResidualNorm<NP>, kChainCP>(P.g_out, P.e_out, bm, bn, ring1);
+        __syncthreads();
+        first = false;
+      }
+    if (first) h2.after_loop();
+  }
+  if (!P.has_qkv) return;
+  xcd_barrier(bar, nslot, P.err);
+  // ---- phase 2: the next layer's fused QKV projection ---------------------------------------------------------------
+  {
+    bool first = true;
+    for (int bm = xcd; bm < nbm; bm += 8)
+      for (int bn = slot; bn < nbn2; bn += nslot) {
+        if (first && bm == xcd && bn == slot) gemm_tile<NP, 64, QKV_BN, 3, EpiQKV<NP>, kChainCP, kPfNone, 1, PS2>(P.g_qkv, P.e_qkv, bm, bn, ring2);
+        else gemm_tile<NP, 64, QKV_BN, 3, EpiQKV<NP>, kChainCP>(P.g_qkv, P.e_qkv, bm, bn, ring2);
+        __syncthreads();
+        first = false;
+      }
+  }
+}
+
+template <int NP, int QKV_BN>
+inline hipError_t mlp_chain_ps_prepare() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_ps_kernel<NP, QKV_BN>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, mlp_chain_ps_smem<NP, QKV_BN>());
+}
+
+template <int NP, int QKV_BN>
+inline hipError_t launch_mlp_chain_ps(const MlpChainParams<NP>& P, int cus, hipStream_t stream) {
+  static const hipError_t attr = mlp_chain_ps_prepare<NP, QKV_BN>();
+  if (attr != hipSuccess) return attr;
+  constexpr int smem = mlp_chain_ps_smem<NP, QKV_BN>();
+  hipLaunchKernelGGL((mlp_chain_ps_kernel<NP, QKV_BN>), dim3(cus), dim3(256 + 64), smem, stream, P);
+  return hipGetLastError();
 }
 
 template <int NP, int QKV_BN>

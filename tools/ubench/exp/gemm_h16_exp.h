@@ -86,18 +86,17 @@ struct EpiAddStoreH16 {
   template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     if (BN != 32) return;
-    __builtin_assume(aux != nullptr);
     for (int i = wave; i < BM / 8; i += 4)
       __builtin_amdgcn_global_load_lds(
           (aux_gptr_t)(addend + (size_t)(m0 + 8 * i + (lane >> 3)) * ld_add + n0 + (lane & 7) * 4),
-          (aux_lptr_t)(aux + i * 1024), 16, 0, CP);
+          lds_ptr_of(aux + i * 1024), 16, 0, CP);
   }
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
                       SatFlag sf = SatFlag()) const {
-    const bool pre = aux && BN == 32;
+    const bool pre = BN == 32 && aux_present(aux);
     typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
     RangeCheck rc;
     for (int item = tid; item < BM * BN / 8; item += 256) {

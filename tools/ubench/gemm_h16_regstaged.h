@@ -2,6 +2,7 @@
 // the ablation micro-benchmarks (tools/ubench/gemm_bench.hip): the product path uses the LDS-DMA kernel of
 // music-spectrogram-diffusion_amd/csrc/gemm_h16.h, which this header includes for the shared pieces.
 #pragma once
+#define MSD_EPI_AUX_OPTIONAL 1   // this kernel has no aux LDS region: the epilogues read their operands from global memory
 #include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
 
 namespace msd {
