@@ -426,7 +426,7 @@ def _overflowing_params(params):
 
 def test_activation_beyond_the_half_range_fails_the_call(tiny_ctx):
   spec, params, _ = tiny_ctx
-  model = msd_amd.InferenceModel(_overflowing_params(params), spec)          # default precision: f16x3
+  model = msd_amd.InferenceModel(_overflowing_params(params), spec, range_fallback=False)   # default precision f16x3; the fallback (on by default) would hide the error
   batch = helpers.make_batch(spec)
   init_z, noise = helpers.make_noise(spec)
   with pytest.raises(msd_amd.native.RangeError, match="bf16x3"):
@@ -454,6 +454,38 @@ def test_range_fallback_switches_to_bfloat16_planes_and_matches_the_oracle(tiny_
   e, e32 = helpers.rms(got, ref64), helpers.rms(ref32, ref64)
   print('[range fallback] rms vs float64 %.3e (float32 oracle %.3e)' % (e, e32))
   assert e <= 4 * e32 + 1e-4
+
+
+def test_range_fallback_fires_in_the_middle_of_a_song():
+  """predict_sequence with the (default) range fallback when the overflow only shows up from segment 1 on.
+  sum_cross_attends gives the context its own cross-attention module: the context encoder's final norm scale times
+  3e5 and that module's key / value kernels divided by 3e5 are the same function in exact arithmetic, but the
+  encodings of an UNMASKED context (segments >= 1) leave the half-plane range.  Segment 0 (context masked: the context
+  encoder does not run) stays on 'f16x3'; segment 1 raises MSD_ERR_RANGE inside msd_encode, the model switches to
+  'bf16x3' with a warning, repeats that segment and finishes the song there."""
+  import dataclasses
+  spec = msd_amd.config.preset('tiny_context', num_steps=4)
+  spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style='sum_cross_attends'))
+  params = dict(msd_amd.synthetic.init_params(spec, 21, norm_scale_jitter=0.1))
+  params['continuous_encoder/encoder_norm/scale'] = (params['continuous_encoder/encoder_norm/scale'] * 3e5).astype(np.float32)
+  for name in list(params):
+    if 'MultiHeadDotProductAttention_1/key/' in name or 'MultiHeadDotProductAttention_1/value/' in name:
+      params[name] = (params[name] / 3e5).astype(np.float32)
+  segs = [msd_amd.synthetic.segment_tokens(spec, k) for k in range(3)]
+  model = msd_amd.InferenceModel(params, spec)                       # range_fallback defaults to True
+  with pytest.warns(RuntimeWarning, match='bf16x3'):
+    song = model.predict_sequence(segs, seed=3)
+  assert model.precision == 'bf16x3' and np.isfinite(song).all()
+  t = spec.task_feature_lengths['targets']
+  # segment 0 is what a model that never fell back computes; segments 1, 2 are what a bfloat16-plane model computes
+  # when resumed on segment 0's prediction
+  strict = msd_amd.InferenceModel(params, spec, range_fallback=False)
+  np.testing.assert_array_equal(strict.predict_sequence(segs[:1], seed=3), song[:, :t])
+  with pytest.raises(msd_amd.native.RangeError):
+    strict.predict_sequence(segs, seed=3)
+  other = msd_amd.InferenceModel(params, spec, precision='bf16x3')
+  rest = other.predict_sequence(segs[1:], seed=3, init_context=song[:, :t], first_segment_index=1)
+  np.testing.assert_array_equal(rest, song[:, t:])
 
 
 def test_a_precision_of_the_other_library_build_is_refused(tiny_ctx):

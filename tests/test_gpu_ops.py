@@ -149,6 +149,70 @@ def test_attention(env, prec, tol, nq, nk, valid, heads):
       assert err < bound, (qp, err)
 
 
+@pytest.mark.parametrize('s_std', [3.5, 10.0, 20.0])
+def test_attention_sharp_logits_by_query_side_planes(env, s_std):
+  """SHARP attention: logits with standard deviation `s_std` -- the top competing keys of a
+  row sit ~2.8 s_std from the mean, i.e. |s| ~ 10 / 30 / 60 -- against the float64 oracle, for each query-side plane
+  choice of the two-plane mode.  What one half plane (11 significand bits) costs where:
+    P (softmax weights, qp bit 1): 2^-12 relative on every weight, whatever the logits  -> flat, ~2e-4 of the output
+    Q (queries, qp bit 0):         a logit moves by ~|s| 2^-12                           -> GROWS with s_std
+  The bounds below are those two laws; a NumPy emulation of the planes (hi = f16(x), lo = f16(x - hi)) gives, for
+  s_std 3.5 / 10 / 20: all planes 4e-7 / 9e-7 / 1.2e-6, P one plane 1.0e-4 / 1.0e-4 / 1.2e-4, Q one plane 8e-4 / 2.3e-3 / 3.3e-3."""
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(int(s_std * 10))
+  nq, nk, heads = 128, 512, 2
+  j = heads * 64
+  scale = np.sqrt(s_std / 8.0)          # q, k ~ N(0, scale^2): q.k over 64 dims has std 8 scale^2
+  q = (rng.standard_normal((nq, j)) * scale).astype(np.float32)
+  k = (rng.standard_normal((nk, j)) * scale).astype(np.float32)
+  v = rng.standard_normal((nk, j)).astype(np.float32)
+  xp = backend.NumpyBackend('float64')
+  sh = lambda x, n: x.reshape(1, n, heads, 64).astype(np.float64)
+  ref = ops.dot_product_attention(xp, sh(q, nq), sh(k, nk), sh(v, nk)).reshape(nq, j)
+  logits = np.einsum('qhd,khd->hqk', q.reshape(nq, heads, 64).astype(np.float64), k.reshape(nk, heads, 64).astype(np.float64))
+  top = np.sort(logits, -1)[..., -1].mean()
+  errs = {}
+  for qp in (0, 2, 1, 3):
+    o = torch.zeros((nq, j), dtype=torch.float32, device='cuda')
+    native.op_attention('f16x3', _dev(torch, q), _dev(torch, k), _dev(torch, v), o, heads, qp=qp)
+    errs[qp] = np.abs(o.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+  print('sharp attention, logit std %.1f (mean top logit %.1f): max err all planes %.2e | P one plane %.2e | Q one plane %.2e | both %.2e'
+        % (s_std, top, errs[0], errs[2], errs[1], errs[3]))
+  q_law = 2.0 * s_std * 2.0 ** -12 + 5e-4
+  assert errs[0] < 2e-5 and errs[2] < 4e-4
+  assert errs[1] < q_law and errs[3] < q_law + 4e-4
+  assert errs[2] < errs[1]   # the P plane is the cheap one to drop, at every sharpness
+
+
+def test_attention_two_equal_keys_at_logit_40(env):
+  """Two keys with EQUAL logits ~40 per query (k_b = k_a reflected about q: q.k_b == q.k_a), far above a soft
+  background: the output is the 50 / 50 mix of their values, and any perturbation of the logit DIFFERENCE moves the
+  mix.  All planes keep it to ~1e-5; one plane for Q moves the two logits by different amounts (~|q| |k_a - k_b| 2^-12)."""
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(40)
+  nq, nbg = 64, 128
+  q = rng.standard_normal((nq, 64)).astype(np.float32)
+  ka = (q * (40.0 / (q * q).sum(-1, keepdims=True)) + 0.4 * rng.standard_normal((nq, 64))).astype(np.float32)
+  kb = (2.0 * (q * ka).sum(-1, keepdims=True) / (q * q).sum(-1, keepdims=True) * q - ka).astype(np.float32)
+  k = np.concatenate([np.stack([ka, kb], 1).reshape(2 * nq, 64), 0.35 * rng.standard_normal((nbg, 64)).astype(np.float32)], 0)
+  v = rng.standard_normal((k.shape[0], 64)).astype(np.float32)
+  xp = backend.NumpyBackend('float64')
+  sh = lambda x, n: x.reshape(1, n, 1, 64).astype(np.float64)
+  ref = ops.dot_product_attention(xp, sh(q, nq), sh(k, k.shape[0]), sh(v, k.shape[0])).reshape(nq, 64)
+  sd = (q.astype(np.float64) * (ka.astype(np.float64) - kb.astype(np.float64))).sum(-1)
+  assert np.abs(sd).max() < 1e-3 and 30 < (q.astype(np.float64) * ka).sum(-1).min()   # equal logits, ~40
+  errs = {}
+  for qp in (0, 2, 1, 3):
+    o = torch.zeros((nq, 64), dtype=torch.float32, device='cuda')
+    native.op_attention('f16x3', _dev(torch, q), _dev(torch, k), _dev(torch, v), o, 1, qp=qp)
+    errs[qp] = np.abs(o.cpu().numpy() - ref).max()
+  print('two equal keys at logit ~40: max err all planes %.2e | P one plane %.2e | Q one plane %.2e | both %.2e'
+        % (errs[0], errs[2], errs[1], errs[3]))
+  assert errs[0] < 5e-5 and errs[2] < 3e-4 and errs[1] < 8e-3 and errs[3] < 8e-3   # (emulation: 1.3e-6 / 1.5e-5 / 3.7e-3 / 3.8e-3)
+
+
 def test_attention_spiked_key_forces_online_rescale(env):
   """A key block whose max jumps by ~60 forces the running-max rescale path."""
   torch, native = env
