@@ -229,7 +229,7 @@ def batched_leg(spec, args):
   import torch
   import msd_amd
   nb = args.batched_songs
-  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb, precision=args.precision)
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb, precision=args.precision, **model_kwargs(args))
   c_len = model.targets_context_length
   pred = torch.zeros((nb, c_len, 128), dtype=torch.float32, device=model.device) if c_len is not None else None
   t_frames = spec.task_feature_lengths['targets']
@@ -259,7 +259,7 @@ def small_leg(args):
   import torch
   import msd_amd
   spec = msd_amd.config.preset('small', num_steps=args.num_steps, cfg_weight=args.cfg_weight)
-  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=1, precision=args.precision)
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=1, precision=args.precision, **model_kwargs(args))
   t_frames = spec.task_feature_lengths['targets']
   n = args.small_segments
   segs = [msd_amd.synthetic.segment_tokens(spec, 5000 + k) for k in range(n + 1)]
@@ -357,6 +357,15 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
     return {'ok': False, 'error': repr(e)[:200]}
 
 
+def model_kwargs(args):
+  """InferenceModel options that are NOT the library default (the default run passes none)."""
+  kw = {}
+  if args.attn_planes:
+    q, p = (int(v) for v in args.attn_planes.split(','))
+    kw['attention_query_planes'] = (q, p)
+  return kw
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -371,6 +380,8 @@ def main():
   ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
   ap.add_argument('--cfg-weight', type=float, default=5.0)
   ap.add_argument('--batch', type=int, default=1, help='independent songs synthesized together per GPU')
+  ap.add_argument('--attn-planes', default='', help='q,p planes of the query side of the decoder attentions (e.g. "1,1" = '
+                  "round 3's single plane); default: the library's choice (hi + lo for both: DESIGN.md 3)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample-steps', type=int, default=20)
   ap.add_argument('--data', choices=['tokens', 'midi'], default='tokens',
@@ -424,7 +435,7 @@ def main():
     dist.all_gather_object(ranks_seen, me)
 
   spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
-  model = _resolve(args.model_factory)('synthetic:0', spec, batch_size=args.batch, precision=args.precision)
+  model = _resolve(args.model_factory)('synthetic:0', spec, batch_size=args.batch, precision=args.precision, **model_kwargs(args))
   nb = args.batch
   t_frames = spec.task_feature_lengths['targets']
   c_len = model.targets_context_length
@@ -587,7 +598,8 @@ def main():
                                   'segment-sequential with context hand-off' if c_len is not None
                                   else 'independent segments (no context), one after the other',
                                   args.steps, t_frames),
-                   'precision': args.precision, 'parallelism': par, 'mode': mode},
+                   'precision': args.precision, 'parallelism': par, 'mode': mode,
+                   'attention_query_planes': args.attn_planes or 'library default: hi + lo for Q and for the softmax weights'},
         'roofline': roofline,
     }
     if mode == 'replicas':

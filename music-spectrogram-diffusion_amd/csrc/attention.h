@@ -402,26 +402,51 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 }
 
 // Finish a key-split attention: out[row][head*64 + d] = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m)
-template <int NP>
+// KS = the split count as a compile-time constant (2, 3, 4; 0 = run-time loop).  With a run-time count the two loops
+// over the splits stayed rolled, each iteration waiting for its own loads: six dependent L2 round trips in a kernel
+// that moves 4 MB -- 2.7 of its 5.0 us (profiles/r03p_phase_times_b1.txt).  Unrolled, the (m, l) pairs and the O rows
+// of every split are in flight together before anything is computed; the sums still run in split order (same bits).
+template <int NP, int KS = 0>
 __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int heads) {
   const int item = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d group)
   const int d0 = (item & 7) * 8, head = (item >> 3) % heads, row = (item >> 3) / heads;
   if (row >= p.total_rows) return;
   MSD_TS_BEGIN(6, blockIdx.x)
   float mt = -1e30f;
-  for (int ks = 0; ks < p.ksplit; ++ks)
-    mt = fmaxf(mt, p.part_ml[(((size_t)ks * p.total_rows + row) * heads + head) * 2]);
   float lt = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int ks = 0; ks < p.ksplit; ++ks) {
-    const size_t base = ((size_t)ks * p.total_rows + row) * heads + head;
-    const float f = fast_exp(p.part_ml[base * 2] - mt);
-    lt += p.part_ml[base * 2 + 1] * f;
-    const float4 a = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0);
-    const float4 b = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0 + 4);
-    acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
-    acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
+  if constexpr (KS > 0) {
+    f32x2 ml[KS];
+    f32x4 oa[KS], ob[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const size_t base = ((size_t)ks * p.total_rows + row) * heads + head;
+      ml[ks] = *reinterpret_cast<const f32x2*>(p.part_ml + base * 2);
+      oa[ks] = *reinterpret_cast<const f32x4*>(p.part_o + base * 64 + d0);
+      ob[ks] = *reinterpret_cast<const f32x4*>(p.part_o + base * 64 + d0 + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) mt = fmaxf(mt, ml[ks][0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float f = fast_exp(ml[ks][0] - mt);
+      lt += ml[ks][1] * f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[e] += oa[ks][e] * f; acc[4 + e] += ob[ks][e] * f; }
+    }
+  } else {
+    for (int ks = 0; ks < p.ksplit; ++ks)
+      mt = fmaxf(mt, p.part_ml[(((size_t)ks * p.total_rows + row) * heads + head) * 2]);
+    for (int ks = 0; ks < p.ksplit; ++ks) {
+      const size_t base = ((size_t)ks * p.total_rows + row) * heads + head;
+      const float f = fast_exp(p.part_ml[base * 2] - mt);
+      lt += p.part_ml[base * 2 + 1] * f;
+      const float4 a = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0);
+      const float4 b = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0 + 4);
+      acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
+      acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
+    }
   }
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
   float v[8];
@@ -508,7 +533,10 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   }
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;
-    hipLaunchKernelGGL((attention_merge_kernel<NP>), dim3((items + 255) / 256), dim3(256), 0, stream, p, heads);
+    const dim3 mg((items + 255) / 256), mb(256);
+    if (p.ksplit == 4) hipLaunchKernelGGL((attention_merge_kernel<NP, 4>), mg, mb, 0, stream, p, heads);
+    else if (p.ksplit == 2) hipLaunchKernelGGL((attention_merge_kernel<NP, 2>), mg, mb, 0, stream, p, heads);
+    else hipLaunchKernelGGL((attention_merge_kernel<NP, 0>), mg, mb, 0, stream, p, heads);
   }
   return hipGetLastError();
 }

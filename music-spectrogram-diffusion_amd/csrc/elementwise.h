@@ -117,12 +117,13 @@ struct SamplerParams {
 };
 
 // model output -> (eps, x0) at the TRAIN schedule's log-SNR (diffusion_utils.py:288-322)
-__device__ __forceinline__ void convert_model_output(int mode, const float* c, float z, float o,
+template <int mode>
+__device__ __forceinline__ void convert_model_output(const float (&c)[kCoefCount], float z, float o,
                                                      float& eps, float& x0) {
-  if (mode == kOutEps) {
+  if constexpr (mode == kOutEps) {
     eps = o;
     x0 = c[kCoefMX0Scale] * (z - o * c[kCoefMX0Eps]);
-  } else if (mode == kOutX0) {
+  } else if constexpr (mode == kOutX0) {
     x0 = o;
     eps = c[kCoefMEpsScale] * (z - o * c[kCoefMEpsX0]);
   } else {  // v: x0 = alpha z - sigma v
@@ -133,13 +134,14 @@ __device__ __forceinline__ void convert_model_output(int mode, const float* c, f
 
 // one element of eval_step.body after the decoder calls (diffusion_utils.py:416-452):
 // o_c / o_u = conditional / unconditional model output, nz = the step's normal draw
-__device__ __forceinline__ float sampler_update(const SamplerParams& p, const float* c, int i, float z,
+template <int MODE>
+__device__ __forceinline__ float sampler_update(const SamplerParams& p, const float (&c)[kCoefCount], int i, float z,
                                                 float o_c, float o_u, float nz) {
   float eps, x0;
-  convert_model_output(p.model_output, c, z, o_c, eps, x0);
+  convert_model_output<MODE>(c, z, o_c, eps, x0);
   if (p.passes == 2) {
     float eps_u, x0_u;
-    convert_model_output(p.model_output, c, z, o_u, eps_u, x0_u);
+    convert_model_output<MODE>(c, z, o_u, eps_u, x0_u);
     eps = p.cond_wt * eps + (1.0f - p.cond_wt) * eps_u;
     x0 = c[kCoefX0Scale] * (z - eps * c[kCoefX0Eps]);
   }
@@ -155,22 +157,34 @@ __device__ __forceinline__ float sampler_update(const SamplerParams& p, const fl
   return (i == 0) ? x0 : zs;
 }
 
+// MODE = p.model_output as a compile-time constant: with the run-time switch the conversions' two results travelled
+// through scratch memory and a maze of scalar branches (885 lines of ISA for an elementwise kernel)
+template <int MODE>
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   // step_from_slot1: the step's first kernel (in_proj) copied the index to slot 1 and nobody else
   // reads slot 0 any more in this step, so this launch may decrement slot 0 itself
   const int i = p.step_from_slot1 ? p.step_ptr[1] : p.step_ptr[0];
-  const float* c = p.coef + (size_t)i * kCoefCount;
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx < p.n) {
-    // native vectors (not float4 structs copied into arrays: those went through 20 bytes of scratch)
+    // Loads that do not depend on the scan index go out first; the coefficient row (20 floats = five 16-byte loads,
+    // rows are 80 bytes apart) and the step's noise follow as soon as the index is here.  The coefficients live in
+    // REGISTERS (a pointer into the table made every c[k] of sampler_update a scalar load inside a branch, with a wait
+    // each, and pushed the kernel into scratch); native vectors instead of float4 structs copied into arrays.
     const f32x4 zz = *reinterpret_cast<const f32x4*>(p.z + idx);
     const f32x4 ec = *reinterpret_cast<const f32x4*>(p.eps + idx);
     f32x4 eu = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
     if (p.passes == 2) eu = *reinterpret_cast<const f32x4*>(p.eps + p.n + idx);
+    static_assert(kCoefCount == 20, "five 16-byte loads per row");
+    f32x4 cr[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cr[k] = reinterpret_cast<const f32x4*>(p.coef + (size_t)i * kCoefCount)[k];
     if (!p.ddim && i != 0) nz = *reinterpret_cast<const f32x4*>(*p.noise_slot + (size_t)i * p.n + idx);
+    float c[kCoefCount];
+#pragma unroll
+    for (int k = 0; k < kCoefCount; ++k) c[k] = cr[k >> 2][k & 3];
     f32x4 out;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = sampler_update(p, c, i, zz[k], ec[k], eu[k], nz[k]);
+    for (int k = 0; k < 4; ++k) out[k] = sampler_update<MODE>(p, c, i, zz[k], ec[k], eu[k], nz[k]);
     *reinterpret_cast<f32x4*>(p.z + idx) = out;
     if (p.z_hi) {
       uint32_t h[2], l[2];
@@ -189,6 +203,13 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
   // (kernel boundary); the decrement is ordered by the same boundary.
   __syncthreads();
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) p.step_ptr[p.step_from_slot1 ? 0 : 1] = i - 1;
+}
+
+inline void launch_sampler_step(const SamplerParams& sp, hipStream_t s) {
+  const dim3 grid((sp.n / 4 + 255) / 256), block(256);
+  if (sp.model_output == kOutX0) hipLaunchKernelGGL(sampler_step_kernel<kOutX0>, grid, block, 0, s, sp);
+  else if (sp.model_output == kOutV) hipLaunchKernelGGL(sampler_step_kernel<kOutV>, grid, block, 0, s, sp);
+  else hipLaunchKernelGGL(sampler_step_kernel<kOutEps>, grid, block, 0, s, sp);
 }
 
 // g[step][slot][k] = gamma[k] * (film_scale[step][slot][k] + 1): the column multiplier of a

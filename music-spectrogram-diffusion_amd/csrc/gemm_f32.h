@@ -150,11 +150,22 @@ __global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(Fi
   const int nbn = p.N / 32;
   const int m0 = (blockIdx.x / nbn) * BMR, n0 = (blockIdx.x % nbn) * 32;
   const int g = lane >> 4, r = lane & 15;
-  // row statistics once per row (wave 0), loads issued before the K loop
+  // row statistics once per row: the 64 lanes of wave 0 take a quarter of a row's partial sums each (lane = quarter x
+  // row), all loads in flight together, two shuffles.  Round 3's form -- one thread per row, a run-time loop -- was 24
+  // DEPENDENT global loads (vmcnt(0) behind each) that the whole block then waited for at its barrier: about 5 of this
+  // kernel's 10.6 us.  (BMR <= 16 rows here; tiles <= 32.)
   float ss = 0.f;
-  if (threadIdx.x < BMR) {
-    const float* q = p.ssq + (size_t)(m0 + threadIdx.x) * p.tiles;
-    for (int t = 0; t < p.tiles; ++t) ss += q[t];
+  float sv[8];   // issued here, reduced BEHIND the K loop: wave 0's operand loads must not queue behind a wait for these
+  static_assert(BMR <= 16, "one wave covers the rows of the tile in quarters");
+  if (wave == 0) {
+    const int row = lane & 15, part = lane >> 4;
+    const int per = (p.tiles + 3) >> 2;                        // partial sums per quarter (<= 8)
+    const float* q = p.ssq + (size_t)(m0 + (row < BMR ? row : 0)) * p.tiles;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = part * per + i;
+      sv[i] = q[(i < per && t < p.tiles) ? t : 0];
+    }
   }
   f32x4 acc[RT][2];
 #pragma unroll
@@ -196,6 +207,13 @@ __global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(Fi
         }
       }
     }
+  }
+  if (wave == 0) {
+    const int part = lane >> 4, per = (p.tiles + 3) >> 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += (i < per && part * per + i < p.tiles) ? sv[i] : 0.f;
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
   }
   if (threadIdx.x < BMR) rstd[threadIdx.x] = 1.0f / sqrtf(ss * p.inv_d + 1e-6f);
   // C layout: col = lane & 15, row = (lane >> 4) * 4 + e

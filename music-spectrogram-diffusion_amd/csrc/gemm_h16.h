@@ -804,8 +804,18 @@ __device__ __forceinline__ void tile_rstd_compute(const RowScale& r, float* rs, 
   const int row = tid / TPR, part = tid % TPR;
   float acc = 0.f;
   if (aux_present(aux)) {
+    // all reads issued together (fixed trip count, clamped index, zero for the tail: same sum order, same bits): the
+    // run-time loop was 6 dependent LDS round trips in front of every consumer epilogue
     lds_cf32 q = (lds_cf32)(aux) + row * r.tiles;
-    for (int t = part; t < r.tiles; t += TPR) acc += q[t];
+    constexpr int MAXIT = kAuxMaxTiles / TPR;
+    float v[MAXIT];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int t = part + i * TPR;
+      v[i] = q[t < r.tiles ? t : part];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) acc += (part + i * TPR < r.tiles) ? v[i] : 0.f;
   } else {
     const float* q = r.ssq + (size_t)(m0 + row) * r.tiles;
     for (int t = part; t < r.tiles; t += TPR) acc += q[t];
@@ -1062,20 +1072,44 @@ struct EpiResidualNorm {
              },
              [&](int n, int, float4& g0, float4& g1) { g0 = f4(gc[n / 4]); g1 = f4(gc[n / 4 + 1]); });
     } else {
+      // The batched path's 128 x 96 tiles come here (no aux copy of the residual tile: it would not fit behind the
+      // ring).  Round 3's form loaded an item's residual and gain rows INSIDE the item loop: a rolled loop whose every
+      // iteration waited twice with vmcnt(0) -- for its own loads and, vmcnt counting stores too, for the previous
+      // iteration's stores -- 12 dependent memory round trips per thread, the 6.9 us "epilogue" of the phase stamps
+      // (profiles/r03p_phase_times_b8.txt).  Now every load of the thread is in flight before the first item is
+      // computed (up to 24 x 16 bytes per thread; the accumulators are dead by now: they live in the slab).
       const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
       const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
-      for (int item = tid; item < BM * BN / 8; item += 256)
-        body(item,
-             [&](int, int, float4* px, float4& a, float4& b) { a = px[0]; b = px[1]; },
-             [&](bool lo_rows, int, int col, float4& g0, float4& g1) {
-               const float* g = lo_rows ? glo : ghi;
-               g0 = *reinterpret_cast<const float4*>(g + col);
-               g1 = *reinterpret_cast<const float4*>(g + col + 4);
-             },
-             [&](int, int col, float4& g0, float4& g1) {
-               g0 = *reinterpret_cast<const float4*>(g2 + col);
-               g1 = *reinterpret_cast<const float4*>(g2 + col + 4);
-             });
+      constexpr int ITEMS = BM * BN / 8, PER = (ITEMS + 255) / 256;
+      f32x4 xa[PER], xb[PER], ga[PER], gb[PER];
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int item = tid + it * 256;
+        if (ITEMS % 256 == 0 || item < ITEMS) {
+          const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+          const int row = m0 + m, col = n0 + n;
+          const f32x4* px = reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + col);
+          xa[it] = px[0]; xb[it] = px[1];
+          const float* g = row < split_row ? glo : ghi;
+          if (g != nullptr) {
+            ga[it] = *reinterpret_cast<const f32x4*>(g + col);
+            gb[it] = *reinterpret_cast<const f32x4*>(g + col + 4);
+          }
+        }
+      }
+      auto f4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int item = tid + it * 256;
+        if (ITEMS % 256 == 0 || item < ITEMS)
+          body(item,
+               [&](int, int, float4*, float4& a, float4& b2) { a = f4(xa[it]); b2 = f4(xb[it]); },
+               [&](bool, int, int, float4& g0, float4& g1) { g0 = f4(ga[it]); g1 = f4(gb[it]); },
+               [&](int, int col, float4& g0, float4& g1) {
+                 g0 = *reinterpret_cast<const float4*>(g2 + col);
+                 g1 = *reinterpret_cast<const float4*>(g2 + col + 4);
+               });
+      }
     }
     rc.commit(sf.p, sf.tag);
   }

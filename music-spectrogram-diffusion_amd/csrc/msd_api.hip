@@ -33,8 +33,11 @@ namespace {
 
 constexpr int kHeadDim = 64;
 // Library default of the decoder attentions' query side under MSD_PREC_F16X3 (msd_config.attn_q_planes /
-// attn_p_planes = 0): see DESIGN.md 3, "sharp attention".
-constexpr int kDefaultQPlanes = 1, kDefaultPPlanes = 1;
+// attn_p_planes = 0): BOTH planes, like the memory side.  Round 3 ran Q and P on one half plane (-2.5 % step time,
+// 1.05 - 1.29x the float32 oracle's error on fixtures whose attention logits are O(1)); on SHARP attention -- every
+// decoder query kernel times 4: competing keys ~10 apart, what a trained model has -- one plane for Q costs 2.8x the
+// float32 floor and one for P 1.25x (tests/diag/sharp_attention_study.py).  One plane stays an opt-in.
+constexpr int kDefaultQPlanes = 2, kDefaultPPlanes = 2;
 
 enum KClass { KC_NORM = 0, KC_GEMM_QKV, KC_ATTN_SELF, KC_GEMM_ATTN_OUT, KC_GEMM_CROSS_Q,
               KC_ATTN_CROSS, KC_GEMM_CROSS_OUT, KC_GEMM_MLP_IN, KC_GEMM_MLP_OUT,
@@ -1453,7 +1456,7 @@ void enqueue_step(Ctx& c, int batch) {
   sp.sat = m->d_sat; sp.sat_tag = (unsigned)KC_SAMPLER + 1u;
   c.begin(KC_SAMPLER);
   sp.step_from_slot1 = m->fold_norm ? 1 : 0;
-  hipLaunchKernelGGL(sampler_step_kernel, dim3((sp.n / 4 + 255) / 256), dim3(256), 0, c.s, sp);
+  launch_sampler_step(sp, c.s);
 #if MSD_EXPERIMENTS
   if (!m->fold_norm) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
 #endif
@@ -2336,7 +2339,7 @@ int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_de
   sp.n = (int)n; sp.passes = passes; sp.cond_wt = cfg->cfg_weight; sp.clip_x0 = cfg->clip_x0;
   sp.ddim = cfg->sampler == MSD_SAMPLER_DDIM; sp.model_output = cfg->model_output;
   sp.z_hi = nullptr; sp.z_lo = nullptr; sp.step_from_slot1 = 1;
-  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, sp);
+  launch_sampler_step(sp, s);
   if (hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
   return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
 }

@@ -28,7 +28,7 @@ class _StubNative:
 
 class StubInferenceModel:
 
-  def __init__(self, checkpoint_path, spec, batch_size=1, precision='f16x3', device=None):
+  def __init__(self, checkpoint_path, spec, batch_size=1, precision='f16x3', device=None, **_unused):
     self.spec = spec
     self.batch_size = batch_size
     self.precision = precision

@@ -74,18 +74,18 @@ def test_film_table_matches_oracle(tiny_ctx):
 
 @pytest.fixture(scope='module')
 def tiny_ctx_default(tiny_ctx):
-  """The same model in the product's DEFAULT attention mode (query side of the decoder's attentions as one half
-  plane); `tiny_ctx` runs all planes for the short-chain statistics (helpers.ALL_PLANES)."""
+  """The same model with the OPT-IN single query-side plane (Q and the softmax weights of the decoder's attentions as
+  one half plane each: round 3's default); `tiny_ctx` is the product's default = all planes."""
   spec, params, _ = tiny_ctx
-  return msd_amd.InferenceModel(params, spec, batch_size=2)
+  return msd_amd.InferenceModel(params, spec, batch_size=2, **helpers.ONE_QUERY_PLANE)
 
 
-@pytest.mark.parametrize('attention', ['all planes', 'default'])
+@pytest.mark.parametrize('attention', ['default', 'one query-side plane'])
 @pytest.mark.parametrize('mask', ['ones', 'zeros', 'ragged'])
 def test_encode_and_single_decoder_pass(tiny_ctx, tiny_ctx_default, mask, attention):
   import torch
   spec, params, model = tiny_ctx
-  if attention == 'default':
+  if attention != 'default':
     model = tiny_ctx_default
   nm = model._get_native()
   batch = helpers.make_batch(spec, batch=2, ctx_mask=mask)

@@ -11,7 +11,10 @@ EXP=$ROOT/tools/ubench/exp/libmsd_amd_exp.so; EXPTS=$ROOT/tools/ubench/exp/libms
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1"
 one() {  # label, env assignments...
   local label=$1; shift
-  env "$@" timeout 150 $B 2>$OUT/${TAG}_err.tmp | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$label]', d['value'], round(d['sample_ms_per_segment'],1))" || { echo "[$label] FAILED"; tail -5 $OUT/${TAG}_err.tmp; }
+  local extra=""
+  for kv in "$@"; do case $kv in B_EXTRA=1) extra="--attn-planes 1,1";; B_EXTRA=2) extra="--attn-planes 2,1";; esac; done
+  [[ "$label" == r04a* ]] && extra=""   # (the r04a build's default IS one plane for Q and P)
+  env "$@" timeout 150 $B $extra 2>$OUT/${TAG}_err.tmp | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$label]', d['value'], round(d['sample_ms_per_segment'],1))" || { echo "[$label] FAILED"; tail -5 $OUT/${TAG}_err.tmp; }
 }
 case $WHAT in
 tests)
@@ -30,6 +33,21 @@ chain)
   MSD_AMD_LIB=$EXPTS timeout 200 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times_launches.txt 2>&1; tail -3 $OUT/${TAG}_phase_times_launches.txt
   MSD_AMD_LIB=$EXPTS MSD_CHAIN=1 timeout 200 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times_chain1.txt 2>&1; tail -5 $OUT/${TAG}_phase_times_chain1.txt
   MSD_AMD_LIB=$EXPTS MSD_CHAIN=2 timeout 200 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times_chain2.txt 2>&1; tail -5 $OUT/${TAG}_phase_times_chain2.txt
+  ;;
+micro)   # round-4 micro-fixes (merge / final-proj / sampler / rstd / batched residual epilogue) against the r04a build,
+         # both with the SAME attention planes; then the batched leg old vs new; then the default (all planes) line
+  OLD=$ROOT/tools/ab/libs/libmsd_amd_r04a.so
+  for r in 1 2 3; do
+    one "r04a 1,1" MSD_AMD_LIB=$OLD X=0
+    one "new 1,1" X=0 B_EXTRA=1
+    one "new default (2,2)" X=0
+    one "new 2,1" X=0 B_EXTRA=2
+  done 2>&1 | tee $OUT/${TAG}_micro_ab.log
+  for r in 1 2; do
+    for L in "MSD_AMD_LIB=$OLD" "X=0"; do
+      env $L timeout 200 python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 --attn-planes 1,1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[batch 8 $L]', d['value'], d['ms_per_step'])"
+    done
+  done 2>&1 | tee $OUT/${TAG}_micro_b8_ab.log
   ;;
 final)
   timeout 1200 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
