@@ -123,10 +123,13 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   const int blk = blockIdx.y / p.ksplit, ks = blockIdx.y % p.ksplit;
   const int head = blockIdx.x, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
-  const int nkeys = p.n_keys[seg];
-  const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
-  // this block's stages: global stage index = ks + i * ksplit, i = 0..nst-1
-  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) / p.ksplit : 0;
+  // n_keys through the VECTOR memory path (an address the compiler cannot prove uniform): as a scalar load it shared
+  // lgkmcnt with the kernel-argument loads, whose first use waits for EVERYTHING scalar -- i.e. for this L2 round trip,
+  // in front of the Q loads and the ring.  As the oldest vector load it is waited for with a counted vmcnt right
+  // before the key loop, with the Q loads and NS ring stages already in flight behind it.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const int nkeys_v = p.n_keys[seg + vzero];   // used (readfirstlane) only BEHIND the prologue's issue block, below
 
   // ---- DMA source addressing -------------------------------------------------------
   // K tile: instruction j (0..15) moves keys 8j..8j+7 of the stage, lane = (r = lane>>3, c' = lane&7),
@@ -187,10 +190,17 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   }
 
   __builtin_amdgcn_sched_barrier(0);
-  // all NS ring slots are free at the start: NS stages go in flight at once
+  // all NS ring slots are free at the start: NS stages go in flight at once -- UNCONDITIONALLY (round 4): whether a
+  // stage exists depends on n_keys, a device word this block has only just requested, and a conditional issue made the
+  // whole ring wait for that round trip (the "entry -> DMAs issued 2.3 - 2.5 us" of the stamps).  A stage beyond the
+  // key count reads rows clamped into the allocation (MSD_A_ISSUE) and is never looked at; the wait below covers it.
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-    if (s < nst) MSD_A_ISSUE(s, s)
+  for (int s = 0; s < NS; ++s) MSD_A_ISSUE(s, s)
+  __builtin_amdgcn_sched_barrier(0);
+  const int nkeys = __builtin_amdgcn_readfirstlane(nkeys_v);
+  const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
+  // this block's stages: global stage index = ks + i * ksplit, i = 0..nst-1
+  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) / p.ksplit : 0;
   MSD_TS_AT(ts_cls, ts_blk, 1)
 
   f32x16 o0, o1;
@@ -209,7 +219,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   int buf = 0;
   for (int st = 0; st < nst; ++st) {
     // stage st must have landed.  Issued so far: stages 0 .. st+NS-2 (0 .. NS-1 at st = 0).
-    if (st == 0 && nst >= NS) {
+    if (st == 0) {   // NS stages were issued, whatever nst is
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");
     } else if (st > 0 && st + NS - 2 < nst && NS > 2) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
@@ -327,6 +337,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #undef MSD_A_ISSUE
   // full-row sum: combine the two half-lanes that share a query
   l_run += __shfl_xor(l_run, 32, 64);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a prologue stage beyond this block's key range may still be landing)
   __syncthreads();  // every wave is done with the K/V ring before it becomes the merge slab
   MSD_TS_AT(ts_cls, ts_blk, 3)
   PrefetchRegsT<PF> pf_keep;   // warm a later GEMM's weights behind the merge below (gemm_h16.h WeightPrefetch)

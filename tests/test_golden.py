@@ -183,14 +183,15 @@ def test_small_trained_like_weights_1000_steps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('gain', [4, 8])
+@pytest.mark.parametrize('gain', [2, 4])
 def test_small_sharp_attention_1000_steps(gain):
   """SHARP attention: every decoder query kernel times `gain` (synthetic.sharp_attention), i.e.
   every attention logit times `gain` -- competing keys 10 - 30 apart instead of the O(1) logits of fresh initialisers.
   Fixture: the float64 oracle's 1000-step `small` segment with those weights plus the float32 oracle's own rms
   (tests/diag/sharp_attention_study.py --golden).  The DEFAULT mode (all planes) must sit on the float32 floor
   (<= 1.3x: the adoption criterion of round 3); the opt-in single query-side plane is run beside it and only has to
-  meet north_star's 1e-3 bar -- its ratio to the floor is printed (emulation: 2.8x at gain 4)."""
+  meet north_star's 1e-3 bar -- its ratio to the floor is printed (emulation: 2.8x at gain 4).  (Gain 8 is no fixture:
+  the segment is then chaotic in float32 itself -- the float32 oracle ends 0.67 rms away from the float64 one.)"""
   from oracle import philox
   path = os.path.join(GOLD, 'small_sharp%d_n1000.npz' % gain)
   if not os.path.exists(path):

@@ -49,6 +49,13 @@ micro)   # round-4 micro-fixes (merge / final-proj / sampler / rstd / batched re
     done
   done 2>&1 | tee $OUT/${TAG}_micro_b8_ab.log
   ;;
+attn)    # attention prologue (unconditional ring issue, n_keys through the vector path) against the r04b build, default mode
+  OLD=$ROOT/tools/ab/libs/libmsd_amd_r04b.so
+  for r in 1 2 3; do
+    one "r04b" MSD_AMD_LIB=$OLD X=0
+    one "new" X=0
+  done 2>&1 | tee $OUT/${TAG}_attn_ab.log
+  ;;
 final)
   timeout 1200 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
