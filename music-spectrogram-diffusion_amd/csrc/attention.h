@@ -80,10 +80,12 @@ constexpr int kAttVBytes = 64 * kAttStageKeys * 2;     // V^T tile [64 d][128 ke
 constexpr int kAttOLD = 68;                            // merge slab row stride (floats)
 constexpr int kAttWStride = 32 * kAttOLD + 64;         // per-wave merge slab (floats)
 
+constexpr int kAttQBytes = 32 * 128;                   // Q tile of one query block and plane: [32 rows][64 d], behind the ring
+
 template <int NP, int NS, int QB>
 constexpr int attention_smem() {
-  return (NS * NP * (kAttKBytes + kAttVBytes) > QB * kAttKG * kAttWStride * 4)
-             ? NS * NP * (kAttKBytes + kAttVBytes)
+  return (NS * NP * (kAttKBytes + kAttVBytes) + QB * NP * kAttQBytes > QB * kAttKG * kAttWStride * 4)
+             ? NS * NP * (kAttKBytes + kAttVBytes) + QB * NP * kAttQBytes
              : QB * kAttKG * kAttWStride * 4;
 }
 
@@ -123,13 +125,6 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   const int blk = blockIdx.y / p.ksplit, ks = blockIdx.y % p.ksplit;
   const int head = blockIdx.x, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
-  // n_keys through the VECTOR memory path (an address the compiler cannot prove uniform): as a scalar load it shared
-  // lgkmcnt with the kernel-argument loads, whose first use waits for EVERYTHING scalar -- i.e. for this L2 round trip,
-  // in front of the Q loads and the ring.  As the oldest vector load it is waited for with a counted vmcnt right
-  // before the key loop, with the Q loads and NS ring stages already in flight behind it.
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const int nkeys_v = p.n_keys[seg + vzero];   // used (readfirstlane) only BEHIND the prologue's issue block, below
 
   // ---- DMA source addressing -------------------------------------------------------
   // K tile: instruction j (0..15) moves keys 8j..8j+7 of the stage, lane = (r = lane>>3, c' = lane&7),
@@ -169,11 +164,16 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     }                                                                                             \
   }
 
-  // ---- Q fragments (B operand of S^T = K.Q^T), straight from global; issued BEFORE the
-  // ring DMAs so that the counted vmcnt waits below see them as the oldest operations ----
-  const size_t qrow = (size_t)seg * p.q_rows_per_seg + blk * kRows + qb * 32 + q_lane;
-  // QS: the partial sums of squares of this lane's query row -- 8 unconditional 16-byte loads (branch-free: a
-  // conditional load on the way into the loop makes hipcc drain the ring's DMAs), issued before everything else
+  // ---- Q tile (B operand of S^T = K.Q^T): LDS-DMA into a region behind the ring, issued BEFORE the ring stages so that
+  // the counted vmcnt waits below see it as the oldest operation.  (Round 3 loaded the Q fragments straight into
+  // registers: ordinary loads beside LDS-DMA make hipcc wait with vmcnt(0) at their first use -- the first S^T MFMA --
+  // i.e. for EVERY prologue stage instead of stage 0; with self-attention's two stages that serialised landing and
+  // compute.)  Layout and source swizzle of the K tile: row = query, 8 chunks of 16 bytes, chunk ^ (row & 7).
+  const size_t qrow0 = (size_t)seg * p.q_rows_per_seg + blk * kRows + qb * 32;
+  const size_t qrow = qrow0 + q_lane;
+  constexpr int NPQ = Q1 ? 1 : NP;                     // planes of Q the products use
+  constexpr int QOFF = NS * STAGE;
+  // QS: the partial sums of squares of this lane's query row -- 8 unconditional 16-byte loads (experiments build only)
   f32x4 qss[QS ? 8 : 1];
   if constexpr (QS) {
     const int n4 = p.q_tiles >> 2;
@@ -181,14 +181,12 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #pragma unroll
     for (int i = 0; i < 8; ++i) qss[i] = sp[i < n4 ? i : 0];
   }
-  frag8 qf[NP][4];
 #pragma unroll
-  for (int pl = 0; pl < NP; ++pl) {
-    const h16_t* qp = p.q[pl] + qrow * p.ldq + head * 64 + hi * 8;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[pl][s] = ld_frag(qp + s * 16);
-  }
-
+  for (int pl = 0; pl < NPQ; ++pl)   // wave (qb, kg) moves rows 8 kg .. 8 kg + 7 of its query block, every plane
+    __builtin_amdgcn_global_load_lds(
+        (gptr_t)(p.q[pl] + (qrow0 + 8 * kg + kr) * p.ldq + head * 64 + kc * 8),
+        (lptr_t)(smem + QOFF + (qb * NP + pl) * kAttQBytes + kg * 1024), 16, 0, 0);
+  frag8 qf[NP][4];   // read from the Q tile behind the first barrier of the key loop
   __builtin_amdgcn_sched_barrier(0);
   // all NS ring slots are free at the start: NS stages go in flight at once -- UNCONDITIONALLY (round 4): whether a
   // stage exists depends on n_keys, a device word this block has only just requested, and a conditional issue made the
@@ -197,7 +195,16 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #pragma unroll
   for (int s = 0; s < NS; ++s) MSD_A_ISSUE(s, s)
   __builtin_amdgcn_sched_barrier(0);
-  const int nkeys = __builtin_amdgcn_readfirstlane(nkeys_v);
+  // n_keys is read HERE, behind the issue block: as a scalar load at the top of the kernel it shared lgkmcnt with the kernel-argument loads, whose first use
+  // waits for everything scalar -- one L2 round trip in front of the whole prologue.  Now it overlaps the ring's landing.
+  // (An explicit scalar load: behind the LDS-DMA builtins the compiler no longer proves the word unclobbered and would
+  // fall back to a VECTOR load -- whose use then waits with vmcnt(0) for the whole ring.  Load and wait in one statement,
+  // SGPR destination: MI355X guide 5.7 form (i); lgkmcnt does not count the LDS-DMA, which is on vmcnt.)
+  int nkeys;
+  {
+    const int* nkp = p.n_keys + seg;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nkeys) : "s"(nkp) : "memory");
+  }
   const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
   // this block's stages: global stage index = ks + i * ksplit, i = 0..nst-1
   const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) / p.ksplit : 0;
@@ -228,6 +235,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     }
     __builtin_amdgcn_s_barrier();   // stage st visible everywhere; compute(st-1) done everywhere
     __builtin_amdgcn_sched_barrier(0);
+    if (st == 0) {   // the Q tile landed with stage 0 (it was issued first): fragments of this lane's query row
+#pragma unroll
+      for (int pl = 0; pl < NPQ; ++pl)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          qf[pl][s4] = *reinterpret_cast<const frag8*>(smem + QOFF + (qb * NP + pl) * kAttQBytes + q_lane * 128 +
+                                                       (((2 * s4 + hi) ^ (q_lane & 7)) << 4));
+    }
 #if MSD_TIMESTAMPS
     if (st == 0) { MSD_TS_AT(ts_cls, ts_blk, 2) }
 #endif

@@ -709,6 +709,18 @@ __device__ __forceinline__ aux_lptr_t lds_ptr_of(const void* generic) {
   return (aux_lptr_t)(size_t)(unsigned)(size_t)generic;
 }
 
+// The scan index (one device word, written by the previous step's sampler launch) as an EXPLICIT scalar load, waited
+// for inside the statement (SGPR destination, MI355X guide 5.7 form (i)).  A plain `*step_ptr` behind the ring's LDS-DMA
+// builtins compiles to a VECTOR load -- the compiler no longer proves the word unclobbered -- and a vector load beside
+// LDS-DMA is waited for with vmcnt(0): the wave stood there until its whole share of the ring had landed, and the
+// block's first barrier with it, before the step-indexed gain / bias rows could even be requested (every launch with
+// such rows: 60 of a step's 111).  lgkmcnt does not count LDS-DMA.  `p` must be wave-uniform (a kernel argument).
+__device__ __forceinline__ int scan_index(const int* p) {
+  int v;
+  asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
 // LDS-DMA of `bytes` contiguous, 16-byte aligned global bytes to dst (linear), one 1 KiB
 // instruction per wave round-robin.  Lanes past the end re-fetch the last chunk; their LDS
 // writes land in the padding (dst needs round_up(bytes, 1024) bytes).
@@ -742,7 +754,7 @@ __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, 
   if (!r.ssq) return;
   aux_dma_linear<CP>(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
   if (r.bias && wave == 3)
-    aux_dma_row(r.bias + (size_t)(*r.step_ptr) * r.bias_step_stride + n0, aux + rowscale_ssq_bytes<BM>(r.tiles), BN * 4, lane);
+    aux_dma_row(r.bias + (size_t)scan_index(r.step_ptr) * r.bias_step_stride + n0, aux + rowscale_ssq_bytes<BM>(r.tiles), BN * 4, lane);
 }
 
 typedef const __attribute__((address_space(3))) float* lds_cf32;   // explicit LDS pointer: ds_read, not flat_load
@@ -1010,9 +1022,9 @@ struct EpiResidualNorm {
       __builtin_amdgcn_global_load_lds(
           (aux_gptr_t)(x + (size_t)(m0 + 8 * i + (lane >> 3)) * ldx + n0 + (lane & 7) * 4),
           lds_ptr_of(aux + i * 1024), 16, 0, CP);
-    const int step = *step_ptr;
-    if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)step * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
-    if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)step * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
+    // (only the two waves that fetch a step-indexed row read the scan index)
+    if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)scan_index(step_ptr) * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
+    if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)scan_index(step_ptr) * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
     if (kExperiments && g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * 128 + 2048, BN * 4, lane);
   }
   template <int BM, int BN, int LD>

@@ -50,9 +50,9 @@ micro)   # round-4 micro-fixes (merge / final-proj / sampler / rstd / batched re
   done 2>&1 | tee $OUT/${TAG}_micro_b8_ab.log
   ;;
 attn)    # attention prologue (unconditional ring issue, n_keys through the vector path) against the r04b build, default mode
-  OLD=$ROOT/tools/ab/libs/libmsd_amd_r04b.so
+  OLD=$ROOT/tools/ab/libs/libmsd_amd_${BASE:-r04b}.so
   for r in 1 2 3; do
-    one "r04b" MSD_AMD_LIB=$OLD X=0
+    one "${BASE:-r04b}" MSD_AMD_LIB=$OLD X=0
     one "new" X=0
   done 2>&1 | tee $OUT/${TAG}_attn_ab.log
   ;;
