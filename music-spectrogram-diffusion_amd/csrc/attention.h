@@ -48,6 +48,8 @@ struct AttnParams {
   // block (q-group, ks) takes stages ks, ks+ksplit, ... and writes its un-normalised partial
   // (O relative to its own max m, and m, l) to the workspace; attention_merge_kernel finishes.
   int ksplit;
+  int ksplit_log2 = 0;  // log2(ksplit); ksplit is a power of two (launch_attention rounds it down): shifts instead of the
+                        // three software integer divisions (~25 dependent instructions each) the kernel ran at its entry
   float* part_o;        // [ksplit][rows][heads*64]
   float* part_ml;       // [ksplit][rows][heads][2]
   int total_rows;       // rows of q over all segments
@@ -98,6 +100,7 @@ constexpr int attention_smem() {
 // Bit 2: the queries are un-normalised, see AttnParams::q_ssq.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
+  warm_kernargs<kernarg_lines<AttnParams>()>();
   if constexpr (kPfWaveAttn && PF != kPfNone) {
     if (threadIdx.x >= QB * kAttKG * 64) {   // the prefetch wave
       const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -122,7 +125,8 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wave / kAttKG, kg = wave % kAttKG;
   // head is the fastest grid axis: the blocks that share one head's K/V land on few XCDs
-  const int blk = blockIdx.y / p.ksplit, ks = blockIdx.y % p.ksplit;
+  const int kl2 = p.ksplit_log2;
+  const int blk = (int)(blockIdx.y >> kl2), ks = (int)(blockIdx.y & (p.ksplit - 1));
   const int head = blockIdx.x, seg = blockIdx.z;
   const int q_lane = lane & 31, hi = lane >> 5;
 
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   }
   const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
   // this block's stages: global stage index = ks + i * ksplit, i = 0..nst-1
-  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) / p.ksplit : 0;
+  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) >> kl2 : 0;
   MSD_TS_AT(ts_cls, ts_blk, 1)
 
   f32x16 o0, o1;
@@ -433,9 +437,12 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 // that moves 4 MB -- 2.7 of its 5.0 us (profiles/r03p_phase_times_b1.txt).  Unrolled, the (m, l) pairs and the O rows
 // of every split are in flight together before anything is computed; the sums still run in split order (same bits).
 template <int NP, int KS = 0>
-__global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int heads) {
+__global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int heads, unsigned inv_heads) {
+  warm_kernargs<kernarg_lines<AttnParams, int, unsigned>()>();
   const int item = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d group)
-  const int d0 = (item & 7) * 8, head = (item >> 3) % heads, row = (item >> 3) / heads;
+  // row = (item / 8) / heads through the host's ceil(2^32 / heads) (exact while (item / 8) * heads < 2^32), no software division
+  const int rh = item >> 3, row = heads > 1 ? (int)__umulhi((unsigned)rh, inv_heads) : rh;
+  const int d0 = (item & 7) * 8, head = rh - row * heads;
   if (row >= p.total_rows) return;
   MSD_TS_BEGIN(6, blockIdx.x)
   float mt = -1e30f;
@@ -537,10 +544,14 @@ inline void launch_attention_qp(const AttnParams& p, int heads, int segs, hipStr
 }
 
 template <int NP>
-inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hipStream_t stream) {
+inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, hipStream_t stream) {
   constexpr int NS = attention_ns<NP>();
   static const hipError_t attr = attention_prepare<NP, NS>();
   if (attr != hipSuccess) return attr;
+  AttnParams p = p_in;
+  p.ksplit_log2 = 0;
+  while ((2 << p.ksplit_log2) <= p.ksplit) ++p.ksplit_log2;
+  p.ksplit = 1 << p.ksplit_log2;   // a power of two (a request for 3 runs as 2): the kernel shifts, it never divides
   if constexpr (NP == 2) {
     switch ((p.qp & 3) | (kExperiments && p.q_ssq ? 4 : 0)) {
       case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
@@ -560,9 +571,10 @@ inline hipError_t launch_attention(const AttnParams& p, int heads, int segs, hip
   if (p.ksplit > 1) {
     const int items = p.total_rows * heads * 8;
     const dim3 mg((items + 255) / 256), mb(256);
-    if (p.ksplit == 4) hipLaunchKernelGGL((attention_merge_kernel<NP, 4>), mg, mb, 0, stream, p, heads);
-    else if (p.ksplit == 2) hipLaunchKernelGGL((attention_merge_kernel<NP, 2>), mg, mb, 0, stream, p, heads);
-    else hipLaunchKernelGGL((attention_merge_kernel<NP, 0>), mg, mb, 0, stream, p, heads);
+    const unsigned inv_heads = heads > 1 ? (unsigned)((0x100000000ull + (unsigned)heads - 1) / (unsigned)heads) : 0u;
+    if (p.ksplit == 4) hipLaunchKernelGGL((attention_merge_kernel<NP, 4>), mg, mb, 0, stream, p, heads, inv_heads);
+    else if (p.ksplit == 2) hipLaunchKernelGGL((attention_merge_kernel<NP, 2>), mg, mb, 0, stream, p, heads, inv_heads);
+    else hipLaunchKernelGGL((attention_merge_kernel<NP, 0>), mg, mb, 0, stream, p, heads, inv_heads);
   }
   return hipGetLastError();
 }

@@ -108,6 +108,30 @@ struct RangeCheck {
   }
 };
 
+// Kernel arguments live in a per-dispatch memory segment that is cold in every cache when a step's kernel starts (a
+// graph replay touches it once per millisecond, between 2 GB of other traffic).  The compiler loads arguments lazily,
+// near their first use, so a kernel with a 300 - 400 byte argument block (GemmParams + epilogue) walked through it in
+// three or four DEPENDENT scalar-load rounds, each a miss to memory, before its first LDS-DMA went out.  warm_kernargs
+// requests one word of each of the block's first LINES cache lines in one burst at the kernel's first instruction: one
+// miss latency instead of three or four; the lazy loads behind it hit the scalar cache.  (Round 4; measured: DESIGN 6.)
+template <int LINES>
+__device__ __forceinline__ void warm_kernargs() {
+  typedef const __attribute__((address_space(4))) uint32_t* kptr_t;
+  kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t t[LINES];
+#pragma unroll
+  for (int k = 0; k < LINES; ++k) t[k] = ka[16 * k];
+#pragma unroll
+  for (int k = 0; k < LINES; ++k) asm volatile("" ::"s"(t[k]));
+}
+template <class... Args>
+constexpr int kernarg_lines() {   // cache lines covered by the explicit arguments (each aligned to 8: pointers inside)
+  int bytes = 0;
+  const int sz[] = {(int)sizeof(Args)...};
+  for (int s : sz) bytes = (bytes + 7) / 8 * 8 + s;
+  return (bytes + 63) / 64;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -161,6 +161,7 @@ __device__ __forceinline__ float sampler_update(const SamplerParams& p, const fl
 // through scratch memory and a maze of scalar branches (885 lines of ISA for an elementwise kernel)
 template <int MODE>
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
+  warm_kernargs<kernarg_lines<SamplerParams>()>();
   // step_from_slot1: the step's first kernel (in_proj) copied the index to slot 1 and nobody else
   // reads slot 0 any more in this step, so this launch may decrement slot 0 itself
   const int i = p.step_from_slot1 ? p.step_ptr[1] : p.step_ptr[0];

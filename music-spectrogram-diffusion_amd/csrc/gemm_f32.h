@@ -142,13 +142,13 @@ constexpr int kFinalProjWaves = 8;   // K is split over the waves of a block (la
 // RT: 16-row MFMA tiles per block (block tile = 16*RT rows x 32 columns)
 template <int RT>
 __global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(FinalProjParams p) {
+  warm_kernargs<kernarg_lines<FinalProjParams>()>();
   constexpr int BMR = 16 * RT;
   __shared__ __attribute__((aligned(16))) float red[kFinalProjWaves][BMR][33];
   __shared__ float rstd[BMR];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nbn = p.N / 32;
-  const int m0 = (blockIdx.x / nbn) * BMR, n0 = (blockIdx.x % nbn) * 32;
+  const int m0 = blockIdx.y * BMR, n0 = blockIdx.x * 32;   // grid (N / 32, M / BMR): no integer division at the entry
   const int g = lane >> 4, r = lane & 15;
   // row statistics once per row: the 64 lanes of wave 0 take a quarter of a row's partial sums each (lane = quarter x
   // row), all loads in flight together, two shuffles.  Round 3's form -- one thread per row, a run-time loop -- was 24

@@ -219,6 +219,23 @@ struct GemmParams {
   int pf_nblk = 0;    // blocks that take part in the prefetch (0 = the whole grid); they are blockIdx.x < pf_nblk
   int xcd_rows = 1;   // LDS-DMA kernel: the 8 XCDs form an xcd_rows x (8 / xcd_rows) grid over (M, N) tiles
   int xcd_walk_n = 0; // order in which an XCD's blocks walk its tiles
+  // block -> tile map, precomputed by the launcher (TileMap::fill): the kernel used to derive it with FIVE software
+  // integer divisions (v_rcp_iflag + a dozen dependent SALU instructions each: ~230 instructions, half a microsecond) in
+  // front of its first LDS-DMA -- in every one of a step's 72 GEMM launches
+  struct TileMap {
+    int nbm = 0, nbn = 0;        // tiles
+    int nbm_x = 1, nbn_x = 1;    // tiles per XCD row / column group
+    int cx_log2 = 3;             // log2 of the column groups (8 / xcd_rows)
+    unsigned inv_nbm_x = 0, inv_nbn_x = 0;   // ceil(2^32 / d): floor(t / d) == umulhi(t, inv) while t * d < 2^32 (d >= 2)
+    void fill(int M, int N, int BM, int BN, int rx) {
+      const int cx = 8 / rx;
+      nbm = M / BM; nbn = N / BN;
+      nbm_x = (nbm + rx - 1) / rx; nbn_x = (nbn + cx - 1) / cx;
+      cx_log2 = cx == 8 ? 3 : (cx == 4 ? 2 : (cx == 2 ? 1 : 0));
+      inv_nbm_x = nbm_x > 1 ? (unsigned)((0x100000000ull + (unsigned)nbm_x - 1) / (unsigned)nbm_x) : 0u;
+      inv_nbn_x = nbn_x > 1 ? (unsigned)((0x100000000ull + (unsigned)nbn_x - 1) / (unsigned)nbn_x) : 0u;
+    }
+  } map;
   int aux_half = 0;      // gemm_h16_pair.h: bytes of aux LDS per 64-row half of the tile (set by its launcher)
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
   unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
@@ -609,6 +626,7 @@ constexpr int pf_threads(int pf) { return kPfWave && pf != kPfNone ? 64 : 0; }  
 template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
 __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  warm_kernargs<kernarg_lines<GemmParams, Epi>()>();
   if constexpr (kPfWave && PF != kPfNone) {
     if (threadIdx.x >= 256) {   // the prefetch wave (only launched with pf_wave)
       prefetch_wave<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0]);
@@ -621,17 +639,20 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(Gemm
   // With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
   // bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
   // traffic when the activations are as large as the weights (N = D projections).
-  const int nbm = p.M / BM, nbn = p.N / BN;
-  const int RX = p.xcd_rows, CX = 8 / RX;
+  // (the divisions are the launcher's: GemmParams::TileMap)
+  const GemmParams::TileMap& tm = p.map;
+  const int RX = p.xcd_rows, CX = 1 << tm.cx_log2;
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
-  const int nbm_x = (nbm + RX - 1) / RX, nbn_x = (nbn + CX - 1) / CX;
+  const int xr = xcd >> tm.cx_log2, xc = xcd & (CX - 1);
   int bm, bn;
   if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
-    bm = (tt / nbn_x) * RX + xcd / CX; bn = (tt % nbn_x) * CX + xcd % CX;
+    const int q = tm.nbn_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbn_x) : tt;   // tt / nbn_x
+    bm = q * RX + xr; bn = (tt - q * tm.nbn_x) * CX + xc;
   } else {              // row tiles fastest (a weight slice stays hot)
-    bm = (tt % nbm_x) * RX + xcd / CX; bn = (tt / nbm_x) * CX + xcd % CX;
+    const int q = tm.nbm_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbm_x) : tt;   // tt / nbm_x
+    bm = (tt - q * tm.nbm_x) * RX + xr; bn = q * CX + xc;
   }
-  if (bn >= nbn || bm >= nbm) return;
+  if (bn >= tm.nbn || bm >= tm.nbm) return;
   gemm_tile<NP, BM, BN, NS, Epi, 0, PF>(p, epi, bm, bn, smem);
 }
 
@@ -1310,10 +1331,12 @@ inline hipError_t gemm_h16_dma_prepare() {
 }
 
 template <int NP, int BM, int BN, int NS, class Epi>
-inline hipError_t launch_gemm_h16_dma(const GemmParams& p, const Epi& epi, hipStream_t stream) {
+inline hipError_t launch_gemm_h16_dma(const GemmParams& p_in, const Epi& epi, hipStream_t stream) {
   constexpr int smem = gemm_h16_dma_smem<NP, BM, BN, NS, Epi>();
   static const hipError_t attr = gemm_h16_dma_prepare<NP, BM, BN, NS, Epi>();
   if (attr != hipSuccess) return attr;
+  GemmParams p = p_in;
+  p.map.fill(p.M, p.N, BM, BN, p.xcd_rows);
   const int rx = p.xcd_rows, cx = 8 / rx;
   const int grid = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
   // one kernel instantiation per number of prefetch targets (single path: see prefetch_weights)

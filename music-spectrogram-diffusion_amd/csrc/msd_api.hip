@@ -1382,7 +1382,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
     fp.x = x; fp.wg = m->w_out_g; fp.ssq = ssq; fp.out = eps;
     fp.M = M; fp.N = m->ND; fp.K = D; fp.tiles = tiles; fp.inv_d = 1.0f / (float)D;
     c.begin(KC_FINAL_PROJ);
-    hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3((M / 16) * (m->ND / 32)), dim3(64 * kFinalProjWaves), 0, c.s, fp);
+    hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3(m->ND / 32, M / 16), dim3(64 * kFinalProjWaves), 0, c.s, fp);
     c.end(KC_FINAL_PROJ);
   } else {
     EpiStoreF32 ef;
@@ -2542,7 +2542,7 @@ int msd_op_final_proj(const float* x_dev, const float* gamma_dev, const float* w
   FinalProjParams fp;
   fp.x = x; fp.wg = wg; fp.ssq = ssq; fp.out = out_dev; fp.M = M; fp.N = n; fp.K = D; fp.tiles = tiles;
   fp.inv_d = 1.0f / (float)D;
-  hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3((M / 16) * (n / 32)), dim3(64 * kFinalProjWaves), 0, s, fp);
+  hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3(n / 32, M / 16), dim3(64 * kFinalProjWaves), 0, s, fp);
   if (hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
   return hipStreamSynchronize(s) == hipSuccess ? MSD_OK : MSD_ERR_HIP;
 }
