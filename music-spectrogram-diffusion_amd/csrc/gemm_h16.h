@@ -570,7 +570,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   int kt = 0;
   // steady state: unconditional DMA of tile kt+NS, tiles kt+2 .. kt+NS-1 stay in flight
   for (; kt + NS < nk; ++kt) MSD_D_STEP(MSD_D_DOISSUE, (NS - 2) * PW)
-  // drain: the last NS tiles are all issued
+  // drain: the last NS tiles are all issued.  Counted waits here too (round 4: the drain waited with vmcnt(0), i.e. at
+  // its first step for ALL remaining tiles instead of the next one): entered at kt = nk - NS, step j needs tile kt + 1
+  // and may leave NS - 2 - j younger tiles in flight.  (nk < NS -- a K shorter than the ring -- keeps vmcnt(0).)
+  if (nk >= NS) {
+    if constexpr (NS >= 4) { if (kt + 1 < nk) { MSD_D_STEP(0, (NS - 2) * PW) ++kt; } }
+    if constexpr (NS >= 3) { if (kt + 1 < nk) { MSD_D_STEP(0, (NS >= 4 ? NS - 3 : NS - 2) * PW) ++kt; } }
+    if constexpr (NS >= 5) { static_assert(NS <= 4, "write the drain ladder for this ring depth"); }
+  }
   for (; kt + 1 < nk; ++kt) MSD_D_STEP(0, 0)
   // last tile
   MSD_D_HALF(0, 0, 0, fa1, fb1, buf, 1, 1, fa0, fb0)
