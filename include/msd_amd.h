@@ -269,6 +269,7 @@ int msd_op_sampler_step(const msd_config* cfg, int step_index, const float* z_de
  * (layers.py:632-666 + the Dense that follows).  folded=1: the decoder's folded-norm epilogues
  * (EpiResidualNorm producer, row-scale + tabulated bias.W consumer); folded=2: the same with the producer as the
  * 4-way split-K launch of the experiments build (tools/ubench/exp; MSD_ERR_UNSUPPORTED in the product library);
+ * folded=3: the producer on the 32 x 48 tiles the decoder uses where they give one tile per CU (d % 48 == 0);
  * folded=0: separate norm kernel.
  * film_scale_dev / film_bias_dev [D] may both be NULL (plain RMSNorm).
  *   x [m,d]  a [m,k]  w1 [k,d]  gamma [d]  w2 [d,n]  x_out [m,d]  h_out [m,n]; m,k,d,n % 64 == 0 */

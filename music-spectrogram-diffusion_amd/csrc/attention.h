@@ -573,7 +573,6 @@ inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, 
     const dim3 mg((items + 255) / 256), mb(256);
     const unsigned inv_heads = heads > 1 ? (unsigned)((0x100000000ull + (unsigned)heads - 1) / (unsigned)heads) : 0u;
     if (p.ksplit == 4) hipLaunchKernelGGL((attention_merge_kernel<NP, 4>), mg, mb, 0, stream, p, heads, inv_heads);
-    else if (p.ksplit == 2) hipLaunchKernelGGL((attention_merge_kernel<NP, 2>), mg, mb, 0, stream, p, heads, inv_heads);
     else hipLaunchKernelGGL((attention_merge_kernel<NP, 0>), mg, mb, 0, stream, p, heads, inv_heads);
   }
   return hipGetLastError();

@@ -347,19 +347,31 @@ template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNon
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem, int ks = 0,
                                           int tile_id = 0, const Hook& hook = Hook()) {
   static_assert(PSN == 0 || (kExperiments && SK == 1 && PSN <= NS), "pre-staged stages: experiments build only");
-  constexpr int WM = BM / 2, WN = BN / 2;
+  // Wave layout.  2 x 2 waves of (BM/2) x (BN/2) by default.  W13 (BN == 48: the 32 x 48 tile, 256 tiles of a
+  // 512 x 768 output = one per CU): three compute waves side by side, each the full 32 rows x 16 columns; wave 3
+  // SHADOWS wave 2 (same fragment reads, same MFMAs, no slab store): it is there for its quarter of the DMA issue, and
+  // a shadow costs no branch in the pinned instruction stream.  (Measured: a wave 3 that skips the reads and MFMAs
+  // behind a wave-uniform branch per slot -- 12 taken branches per K-tile in every wave -- made the K = 2048 launch
+  // 12.5 -> 16.2 us, profiles/r04k_*.)  The K order of every output element is the same in both layouts (and in every
+  // tile shape): results do not depend on the tile a GEMM runs on.
+  constexpr bool W13 = BN == 48;
+  static_assert(!W13 || (NP == 2 && BM == 32 && SK == 1 && PSN == 0), "1 x 3 wave layout: 32 x 48 tiles, two planes");
+  constexpr int WM = W13 ? BM : BM / 2, WN = W13 ? 16 : BN / 2;
   constexpr int BNE = BN / SK;                    // columns of the tile this block's epilogue owns
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE_BYTES = NP * (A_BYTES + B_BYTES);
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // DMA instructions per wave per plane
-  constexpr int PW = NP * (A_LD + B_LD);          // DMA instructions per wave per K-tile
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // DMA instructions per wave per plane (B_LD: 2 x 2 layout only)
+  // B-operand DMA instructions per wave per K-tile.  2 x 2: wave w owns rows [w BN/4, +BN/4) of BOTH planes (B_LD
+  // instructions each).  W13: 48 rows are not 4 x 8k, so wave w owns rows [(w & 1) 24, +24) of plane w >> 1.
+  constexpr int B_Q = W13 ? BN / 16 : NP * B_LD;
+  constexpr int PW = NP * A_LD + B_Q;             // DMA instructions per wave per K-tile
   constexpr int LDS_LD = BN + kSlabPad;
   static_assert((BM * LDS_LD + BM) * 4 <= NS * STAGE_BYTES, "epilogue slab must fit the operand LDS");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = W13 ? 0 : wave >> 1, wn = W13 ? (wave < 2 ? wave : 2) : wave & 1;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // this wave DMAs rows [wave*BM/4, +BM/4) of every A plane and [wave*BN/4, +BN/4) of every
@@ -370,26 +382,41 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
     ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
-    gb[pl] = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
+    gb[pl] = W13 ? p.B[wave >> 1] + (size_t)(n0 + (wave & 1) * (BN / 2) + r8) * p.ldb + csrc * 8   // (one plane per wave)
+                 : p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
   }
   const size_t a_step = (size_t)8 * p.lda, b_step = (size_t)8 * p.ldb;
 #define MSD_A_SRC(PL, I, K0) (ga[PL] + (I) * a_step + (K0))
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-#define MSD_D_ISSUE(KT, BUF)                                                                \
-  {                                                                                         \
-    char* base_ = smem + (BUF) * STAGE_BYTES;                                               \
-    const int k0_ = (KT) * kGemmBK;                                                         \
-    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                     \
-      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                      \
-          __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl, i, k0_)),                  \
-              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, CP); \
-      _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                      \
-          __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl] + i * b_step + k0_),             \
-              (lptr_t)(base_ + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * i) * 128), 16, 0, 0); \
-    }                                                                                       \
+  // DMA number Q (0 .. PW) of this wave for K-tile KT into ring slot BUF.  2 x 2 layout: plane-major, A rows then B
+  // rows of a plane.  W13: the A instruction of each plane, then this wave's B_Q instructions of its one B plane.
+#define MSD_D_ISSUE1(KT, BUF, Q)                                                             \
+  {                                                                                          \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                                \
+    const int k0_ = (KT) * kGemmBK;                                                          \
+    if constexpr (W13) {                                                                     \
+      if ((Q) < NP * A_LD)                                                                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC((Q) / A_LD, (Q) % A_LD, k0_)),   \
+            (lptr_t)(base_ + ((Q) / A_LD) * A_BYTES + (wave * (BM / 4) + 8 * ((Q) % A_LD)) * 128), 16, 0, CP); \
+      else                                                                                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[0] + ((Q) - NP * A_LD) * b_step + k0_), \
+            (lptr_t)(base_ + NP * A_BYTES + (wave >> 1) * B_BYTES +                          \
+                     ((wave & 1) * (BN / 2) + 8 * ((Q) - NP * A_LD)) * 128), 16, 0, 0);      \
+    } else {                                                                                 \
+      constexpr int AB_ = A_LD + (B_LD ? B_LD : 1);                                          \
+      const int     pl_ = (Q) / AB_, r_ = (Q) % AB_;                                         \
+      if (r_ < A_LD)                                                                         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl_, r_, k0_)),                  \
+            (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, CP);  \
+      else                                                                                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl_] + (r_ - A_LD) * b_step + k0_),     \
+            (lptr_t)(base_ + NP * A_BYTES + pl_ * B_BYTES + (wave * (BN / 4) + 8 * (r_ - A_LD)) * 128), 16, 0, 0); \
+    }                                                                                        \
   }
+#define MSD_D_ISSUE(KT, BUF)                                                                \
+  { _Pragma("unroll") for (int q0_ = 0; q0_ < PW; ++q0_) MSD_D_ISSUE1(KT, BUF, q0_) }
 
   f32x4 acc[FM][FN];
 #pragma unroll
@@ -468,23 +495,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // CU's address unit (64 B/clk, shared by the four waves) drains them -- the ablation in
   // tools/ubench/gemm_abl.hip showed DMA, LDS-read and MFMA time ADDING UP (0.28 + 0.19 +
   // 0.27 us per 64x96 K-tile) instead of overlapping.  Each slot is pinned by a sched_barrier.
-  constexpr int RD = NP * (FM + FN);                    // ds_read_b128 per half step (== PW)
+  constexpr int RD = NP * (FM + FN);                    // ds_read_b128 per half step (== PW in the 2 x 2 layout)
   constexpr int MQ = (NP == 2 ? 3 : 1) * FM * FN;       // MFMAs per half step
-  constexpr int MPR = MQ / RD;                          // MFMAs per slot (remainder in the last)
-  static_assert(PW == RD, "one DMA and one fragment read per slot");
-  // DMA number Q of K-tile KT into slot BUF (same enumeration as MSD_D_ISSUE)
-#define MSD_D_ISSUE1(KT, BUF, Q)                                                             \
-  {                                                                                          \
-    const int     pl_ = (Q) / (A_LD + B_LD), r_ = (Q) % (A_LD + B_LD);                       \
-    char* base_ = smem + (BUF) * STAGE_BYTES;                                                \
-    const int k0_ = (KT) * kGemmBK;                                                          \
-    if (r_ < A_LD)                                                                           \
-      __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl_, r_, k0_)),                    \
-          (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, CP);    \
-    else                                                                                     \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl_] + (r_ - A_LD) * b_step + k0_),       \
-          (lptr_t)(base_ + NP * A_BYTES + pl_ * B_BYTES + (wave * (BN / 4) + 8 * (r_ - A_LD)) * 128), 16, 0, 0); \
-  }
+  constexpr int SLOTS = RD > PW ? RD : PW;              // slots per half step: slot q = [DMA q | read q | MFMAs]
+  constexpr int MPR = MQ / SLOTS;                       // MFMAs per slot (remainder in the last)
+  static_assert(W13 || PW == RD, "one DMA and one fragment read per slot");
   // fragment read number Q of half KK of the tile in slot BUF
 #define MSD_D_READ1(FA, FB, BUF, KK, Q)                                                      \
   {                                                                                          \
@@ -517,10 +532,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // MFMAs on FAc/FBc
 #define MSD_D_HALF(DO_ISSUE, KT, BUF_I, FAn, FBn, BUF_R, KK, DO_READ, FAc, FBc)              \
   {                                                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < RD; ++q_) {                                      \
-      if (DO_ISSUE) MSD_D_ISSUE1(KT, BUF_I, q_)                                              \
-      if (DO_READ) MSD_D_READ1(FAn, FBn, BUF_R, KK, q_)                                      \
-      _Pragma("unroll") for (int e_ = q_ * MPR; e_ < (q_ + 1 == RD ? MQ : (q_ + 1) * MPR); ++e_) \
+    _Pragma("unroll") for (int q_ = 0; q_ < SLOTS; ++q_) {                                   \
+      if (DO_ISSUE && q_ < PW) MSD_D_ISSUE1(KT, BUF_I, q_)                                   \
+      if (DO_READ && q_ < RD) MSD_D_READ1(FAn, FBn, BUF_R, KK, q_)                           \
+      _Pragma("unroll") for (int e_ = q_ * MPR; e_ < (q_ + 1 == SLOTS ? MQ : (q_ + 1) * MPR); ++e_) \
         MSD_D_MFMA1(FAc, FBc, e_)                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
@@ -598,6 +613,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   auto store_slab = [&]() {
+    if (W13 && wave == 3) return;   // (the shadow wave: wave 2 stores these values)
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1038,26 +1054,86 @@ struct EpiResidualNorm {
   h16_t* y2[2] = {nullptr, nullptr};
   const float* g2 = nullptr;
   int y2_rows = 0;
-  // aux layout (BN == 32 only): [x tile BM x 32 fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB][g2 slice, 1 KiB]
-  template <int BM, int BN> static constexpr int aux_bytes() { return BN == 32 ? BM * 128 + 3072 : 0; }
+  // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB][g2 slice, 1 KiB]
+  template <int BN> static constexpr bool narrow() { return BN == 32 || BN == 48; }
+  template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 3072 : 0; }
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    if (BN != 32) return;
-    // rows of 128 B: lane (r = lane>>3, c = lane&7) fetches 16 B of row 8i + r
-    for (int i = wave; i < BM / 8; i += 4)
-      __builtin_amdgcn_global_load_lds(
-          (aux_gptr_t)(x + (size_t)(m0 + 8 * i + (lane >> 3)) * ldx + n0 + (lane & 7) * 4),
-          lds_ptr_of(aux + i * 1024), 16, 0, CP);
+    if (!narrow<BN>()) return;
+    // the residual tile, row-major: 16-byte chunk id = 64 i + lane is chunk id % (BN/4) of row id / (BN/4)
+    // (BN == 32: lane (r = lane>>3, c = lane&7) fetches 16 B of row 8i + r)
+    constexpr int CPR = BN / 4;
+    static_assert((BM * CPR) % 64 == 0, "whole DMA instructions");
+    for (int i = wave; i < BM * CPR / 64; i += 4) {
+      const int id = i * 64 + lane, r = id / CPR, ch = id % CPR;
+      __builtin_amdgcn_global_load_lds((aux_gptr_t)(x + (size_t)(m0 + r) * ldx + n0 + ch * 4),
+                                       lds_ptr_of(aux + i * 1024), 16, 0, CP);
+    }
     // (only the two waves that fetch a step-indexed row read the scan index)
-    if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)scan_index(step_ptr) * g_lo_stride + n0, aux + BM * 128, BN * 4, lane);
-    if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)scan_index(step_ptr) * g_hi_stride + n0, aux + BM * 128 + 1024, BN * 4, lane);
-    if (kExperiments && g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * 128 + 2048, BN * 4, lane);
+    if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)scan_index(step_ptr) * g_lo_stride + n0, aux + BM * BN * 4, BN * 4, lane);
+    if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)scan_index(step_ptr) * g_hi_stride + n0, aux + BM * BN * 4 + 1024, BN * 4, lane);
+    if (kExperiments && g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * BN * 4 + 2048, BN * 4, lane);
+  }
+  // 32 x 48 tiles: 8 lanes per row, 6 of them with 8 columns each; ONE partial sum of squares per row and tile, in
+  // slot n0 / 48 of the row's `tiles` (= D / 32) slots -- the D / 48 slots a row gets this way are fewer than `tiles`,
+  // so the tiles of the first columns also zero one of the unused slots each: a consumer adds all `tiles` slots of a
+  // row whichever launch produced that row (rows of one x are produced by launches of different tile widths).
+  template <int BM, int LD>
+  __device__ void run48(float* s0, int m0, int n0, int tid, const char* aux, SatFlag sf) const {
+    constexpr int BN = 48;
+    static_assert(BM * 8 == 256, "one 8-lane group per row");
+    typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
+    lds_cf32x4 xs = (lds_cf32x4)(aux);
+    lds_cf32x4 gl = (lds_cf32x4)(aux + BM * BN * 4), gh = (lds_cf32x4)(aux + BM * BN * 4 + 1024);
+    const int m = tid >> 3, c = tid & 7;
+    const bool act = c < BN / 8;
+    const int n = act ? c * 8 : 0;
+    const int row = m0 + m, col = n0 + n;
+    float v[8];
+    tile_row8<LD>(s0, m, n, v);
+    const f32x4 a = xs[(m * BN + n) / 4], b = xs[(m * BN + n) / 4 + 1];
+    v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+    v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    float4* px = reinterpret_cast<float4*>(x + (size_t)row * ldx + col);
+    if (act) {
+      px[0] = make_float4(v[0], v[1], v[2], v[3]);
+      px[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
+    sq = act ? sq : 0.f;
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    const int slot = n0 / BN, used = ldx / BN;   // (ldx == D: the residual stream is [rows][D])
+    if (c == 0) ssq[(size_t)row * tiles + slot] = sq;
+    if (c == 6 && used + slot < tiles) ssq[(size_t)row * tiles + used + slot] = 0.f;
+    RangeCheck rc;
+    if (kExperiments && g2 != nullptr && act && row < y2_rows) {
+      lds_cf32x4 gc = (lds_cf32x4)(aux + BM * BN * 4 + 2048);
+      const f32x4 c0 = gc[n / 4], c1 = gc[n / 4 + 1];
+      const float w[8] = {v[0] * c0[0], v[1] * c0[1], v[2] * c0[2], v[3] * c0[3],
+                          v[4] * c1[0], v[5] * c1[1], v[6] * c1[2], v[7] * c1[3]};
+      store_h16x8<NP>(y2, (size_t)row * ldx + col, w, rc);
+    }
+    const bool lo_rows = row < split_row;
+    if (act && (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr))) {
+      const f32x4 g0 = lo_rows ? gl[n / 4] : gh[n / 4], g1 = lo_rows ? gl[n / 4 + 1] : gh[n / 4 + 1];
+      v[0] *= g0[0]; v[1] *= g0[1]; v[2] *= g0[2]; v[3] *= g0[3];
+      v[4] *= g1[0]; v[5] *= g1[1]; v[6] *= g1[2]; v[7] *= g1[3];
+      store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
+    }
+    rc.commit(sf.p, sf.tag);
   }
   template <int BM, int BN, int LD>
   __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
                       SatFlag sf = SatFlag()) const {
+    if constexpr (BN == 48) {
+      return run48<BM, LD>(s0, m0, n0, tid, aux, sf);
+    } else {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
     const bool pre = BN == 32 && aux_present(aux);
     const int step = pre ? 0 : *step_ptr;
@@ -1152,6 +1228,7 @@ struct EpiResidualNorm {
       }
     }
     rc.commit(sf.p, sf.tag);
+    }
   }
 };
 

@@ -183,6 +183,7 @@ struct msd_model {
   int chain_mode = 0;          // MSD_CHAIN's value: 1 = round 2's chain, 2 = with pre-staged weights (round 4)
   bool pf_kv = false;          // QKV launch also warms the layer's cached cross-attention K / V^T (MSD_PF_KV)
   bool big_pair = false, big_wide = false, big_ls = false;   // batched tile variants (MSD_BIG_PAIR / _WIDE / _LS)
+  bool tile48 = true;          // MSD_TILE48=0: the N = D projections stay on 32 x 32 / 64 x 32 tiles (round 3's shapes)
   unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
   int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
   bool hoist_q = false;        // hoisted cross-attention query projection (MSD_HOIST_Q)
@@ -522,11 +523,16 @@ inline int big_m_threshold() {   // rows from which the 128-row tiles are used (
 constexpr int big_m_threshold() { return 2048; }   // rows from which the 128-row tiles are used
 #endif
 
+// epilogues that run on 32 x 48 tiles (gemm_h16.h EpiResidualNorm::run48)
+template <class Epi> struct epi_takes_48 : std::false_type {};
+template <> struct epi_takes_48<EpiResidualNorm<2>> : std::true_type {};
+
 // The tile a GEMM of kind TK runs on, (BM, BN): ONE rule for the launch below and for whoever prefetches that
 // launch's weights (the prefetcher needs the consumer's column tile and XCD grid).
 struct TileShape { int bm, bn; };
+constexpr int kWide48 = 48;
 template <int NP, int TK>
-TileShape pick_tile(int M, int N, int align) {
+TileShape pick_tile(int M, int N, int align, bool wide48 = false, int K = 0) {
   const bool big = NP == 2 && M >= big_m_threshold() && M % 128 == 0;
   if (TK == TK_QKV) {
     if (NP == 2) {
@@ -545,15 +551,28 @@ TileShape pick_tile(int M, int N, int align) {
     return {64, 64};
   }
   if (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE) && big && N % 96 == 0) return {128, 96};   // N = D projections of a decoder layer
-  if (TK == TK_TALL && M % 64 == 0 && tile_cost(M, N, 64, kNarrowTile) <= tile_cost(M, N, kNarrowTile, kNarrowTile))
-    return {64, kNarrowTile};
-  return {kNarrowTile, kNarrowTile};
+  // 32 x 48 (round 4; residual + folded-norm epilogue only): 512 x 768 outputs are 256 such tiles -- one per CU with
+  // 80 operand rows per K-tile, where 32 x 32 is 384 blocks (two on half the CUs: 128 rows) and 64 x 32 is 192 (96
+  // rows on three quarters of the chip)
+  long best = tile_cost(M, N, kNarrowTile, kNarrowTile);
+  TileShape t = {kNarrowTile, kNarrowTile};
+  if (TK == TK_TALL && M % 64 == 0 && tile_cost(M, N, 64, kNarrowTile) <= best) { best = tile_cost(M, N, 64, kNarrowTile); t = {64, kNarrowTile}; }
+  // ... for long K only: the tile's head and tail are heavier than the 64 x 32 tile's (256 blocks' worth of aux rows,
+  // 8 lanes per row in the epilogue), its K-tile is lighter (20 KiB against 24); measured per launch at K = 768: 7.05 us
+  // against 6.65 on 64 x 32, at K = 2048: 12.45 against 12.97 (profiles/r04i_*, r04j_*)
+  if (NP == 2 && wide48 && K >= 1536 && N % kWide48 == 0 && tile_cost(M, N, kNarrowTile, kWide48) < best) t = {kNarrowTile, kWide48};
+  return t;
 }
 
 template <int NP, int TK, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi, int align = 0, const WeightPrefetch* pf = nullptr) {
-  const TileShape t = pick_tile<NP, TK>(M, N, align);
+#if MSD_EXPERIMENTS
+  const bool wide48 = epi_takes_48<Epi>::value && c.m->tile48;
+#else
+  constexpr bool wide48 = epi_takes_48<Epi>::value;
+#endif
+  const TileShape t = pick_tile<NP, TK>(M, N, align, wide48, K);
 #define MSD_GO(BM_, BN_, NS_) return gemm_t<NP, BM_, BN_, NS_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf)
 // Batched songs: 128-row tiles, 2-deep ring of K = 64 tiles.  A 4-deep ring of K = 32 tiles (64-byte rows, its own
 // swizzle and a plain one-barrier-per-tile loop: tools/ubench/gemm_h16_k32.h) was built in round 3, is parity-green on
@@ -593,6 +612,9 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     }
     if constexpr (TK == TK_TALL) {
       if (t.bm == 64) MSD_GO(64, kNarrowTile, kTallNS);
+    }
+    if constexpr (NP == 2 && epi_takes_48<Epi>::value) {
+      if (t.bn == kWide48) MSD_GO(kNarrowTile, kWide48, 4);
     }
     MSD_GO(kNarrowTile, kNarrowTile, 4);
   }
@@ -649,6 +671,7 @@ hipError_t prepare_gemms() {
     PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiQKV<NP>) PREP(128, 128, 2, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreH16<NP>)
+    PREP(32, kWide48, 4, EpiResidualNorm<NP>)
   }
   PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreH16<NP>)
   PREP(32, 32, 4, EpiStoreF32) PREP(32, 32, 4, EpiInProj<NP>)
@@ -1280,7 +1303,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
       }
     } else
 #endif
-    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
+    gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
@@ -1506,6 +1529,7 @@ void exp_read_env(msd_model* m) {
   if (const char* v = getenv("MSD_BIG_PAIR")) m->big_pair = atoi(v) != 0;
   if (const char* v = getenv("MSD_BIG_WIDE")) m->big_wide = atoi(v) != 0;
   if (const char* v = getenv("MSD_BIG_LS")) m->big_ls = atoi(v) != 0;
+  if (const char* v = getenv("MSD_TILE48")) m->tile48 = atoi(v) != 0;
   if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
   if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
   if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
@@ -2411,6 +2435,9 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
         e = launch_gemm_h16_splitk<2, kSkBM, kSkBN, kSkNS, kSkSplit>(p1, er, s);
       }
 #endif
+    } else if (folded == 3) {   // the producer on 32 x 48 tiles (one partial sum per row and tile + zeroed spare slots)
+      if (D % kWide48 || M % 32) return MSD_ERR_INVALID_ARGUMENT;
+      if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, kWide48, 4>(p1, er, s);
     } else if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, 32, 4>(p1, er, s);
     EpiStoreF32 ef;
     ef.out = h_out_dev; ef.ldc = N;
