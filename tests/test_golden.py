@@ -183,7 +183,7 @@ def test_small_trained_like_weights_1000_steps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('gain', [2, 4])
+@pytest.mark.parametrize('gain', [1, 2, 4])
 def test_small_sharp_attention_1000_steps(gain):
   """SHARP attention: every decoder query kernel times `gain` (synthetic.sharp_attention), i.e.
   every attention logit times `gain` -- competing keys 10 - 30 apart instead of the O(1) logits of fresh initialisers.
