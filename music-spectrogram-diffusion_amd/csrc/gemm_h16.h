@@ -970,39 +970,31 @@ struct EpiQKV {
         }
       });
     } else {
-      // transposed items: (column n, 8 consecutive rows = keys).  Keys o..o+7 of a
-      // 16-group land on two runs of 4 consecutive permuted positions.
+      // transposed items: (column n, 8 rows = keys of one 16-key group).  The key permutation inside a group puts keys
+      // {0-3, 8-11} on positions 0 .. 7 and keys {4-7, 12-15} on positions 8 .. 15 (vt_perm16), so an item that takes
+      // rows 4h + {0..3} and 8 + 4h + {0..3} of its group writes ONE 16-byte run per plane (round 4; before: 8
+      // consecutive rows = two 8-byte runs per plane, and the blocks of the V columns were the launch's last to leave:
+      // slab -> stores issued 1.46 us against 0.71 on the Q / K columns, profiles/r04z_phase_times.txt)
       const bool folded = rsc.ssq != nullptr;
+      static_assert(BM % 16 == 0, "whole 16-key groups");
       MSD_EPI_ITEMS(BM * BN / 8, item) {
-        const int n = item / (BM / 8), mm = (item % (BM / 8)) * 8;
+        const int n = item / (BM / 8), q = item % (BM / 8), kg = q >> 1, hh = q & 1;
+        const int r0 = kg * 16 + 4 * hh;            // rows r0 .. r0+3 and r0+8 .. r0+11
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = s0[(mm + e) * LD + n];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = s0[(r0 + e) * LD + n];
+          v[4 + e] = s0[(r0 + 8 + e) * LD + n];
+        }
         if (folded) {
-          float r8[8];
-          tile_row8<1>(rs, 0, mm, r8);   // rs[mm .. mm + 7]
+          const float4 ra = *reinterpret_cast<const float4*>(rs + r0), rb = *reinterpret_cast<const float4*>(rs + r0 + 8);
           const float bn = bias.present ? bias.at(n) : 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * r8[e] + bn;
+          v[0] = v[0] * ra.x + bn; v[1] = v[1] * ra.y + bn; v[2] = v[2] * ra.z + bn; v[3] = v[3] * ra.w + bn;
+          v[4] = v[4] * rb.x + bn; v[5] = v[5] * rb.y + bn; v[6] = v[6] * rb.z + bn; v[7] = v[7] * rb.w + bn;
         }
-        const int mg = m0 + mm, seg = mg / seg_len, key = mg % seg_len;
-        h16_t* base[2];
-        const size_t row = ((size_t)seg * vt_rows + (n0 + n - v_start)) * vt_ld + (key & ~15);
-        base[0] = vt[0] + row;
-        base[1] = vt[NP - 1] + row;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int kp = vt_perm16((key & 15) + 4 * hh);
-          uint32_t h[2], l[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            rc.see(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1]);
-            if (NP == 2) split2_h16(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1], h[e], l[e]);
-            else h[e] = cvt2_h16(v[4 * hh + 2 * e], v[4 * hh + 2 * e + 1]);
-          }
-          *reinterpret_cast<uint2*>(base[0] + kp) = make_uint2(h[0], h[1]);
-          if (NP == 2) *reinterpret_cast<uint2*>(base[1] + kp) = make_uint2(l[0], l[1]);
-        }
+        const int mg = m0 + kg * 16, seg = mg / seg_len, key = mg % seg_len;   // (a 16-group never straddles a segment)
+        const size_t off = ((size_t)seg * vt_rows + (n0 + n - v_start)) * vt_ld + key + 8 * hh;
+        store_h16x8<NP>(vt, off, v, rc);
       }
     }
     rc.commit(sf.p, sf.tag);
