@@ -498,3 +498,42 @@ def test_a_precision_of_the_other_library_build_is_refused(tiny_ctx):
   with pytest.raises(NotImplementedError, match='libmsd_amd.so'):
     msd_amd.native.NativeModel(cfg, planes='bf16')
   assert msd_amd.native.NativeModel(msd_amd.inference._to_native_config(spec, model.audio_codec, 1, 'bf16')).planes == 'bf16'
+
+
+def test_base_size_decoder_pass_does_not_depend_on_the_batch():
+  """base_with_context shapes at 1, 2 and 3 songs per handle: M = 512 / 1024 / 1536 decoder rows pick different tiles
+  (one song: 32 x 48 MLP-out at one tile per CU and 64 x 32 attention-out; 2 - 3 songs: two / three rounds of the same
+  tiles, key split 2 instead of 4 -- msd_api.hip pick_tile, cross_ksplit_for), all below the 128-row tiles of the
+  batched path.  An output element's K order does not depend on its tile, so a song's decoder pass must come out the
+  same whichever batch it sits in (up to the key-split grouping of the cross-attention: float32 rounding), and equal
+  songs in one batch must be BIT-identical.  (The single-song pass itself is pinned to the reference by
+  tests/test_ref_golden.py's full-size fixture.)"""
+  import torch
+  spec = msd_amd.config.preset('base_with_context', num_steps=4)
+  params = msd_amd.synthetic.init_params(spec, 0)
+  one = helpers.make_batch(spec, batch=1, ctx_mask='ragged')
+  z1 = np.random.default_rng(5).standard_normal((1, 256, 128)).astype(np.float32)
+  outs = {}
+  for B in (1, 2, 3):
+    model = msd_amd.InferenceModel(params, spec, batch_size=B)
+    nm = model._get_native()
+    toks = np.repeat(one['encoder_input_tokens'], B, 0)
+    ctx = torch.as_tensor(np.repeat(one['encoder_continuous_inputs'], B, 0)).cuda()
+    mask = np.repeat(one['encoder_continuous_mask'], B, 0)
+    nm.encode(B, toks, ctx, mask)
+    z = torch.as_tensor(np.repeat(z1, B, 0)).cuda()
+    for step, cond in ((3, True), (0, False)):
+      eps = torch.zeros_like(z)
+      nm.decoder_pass(B, step, z, cond, eps)
+      torch.cuda.synchronize()
+      outs[B, step] = eps.cpu().numpy()
+    del model, nm
+    torch.cuda.empty_cache()
+  for step in (3, 0):
+    ref = outs[1, step][0]
+    for B in (2, 3):
+      for j in range(1, B):
+        np.testing.assert_array_equal(outs[B, step][j], outs[B, step][0])
+      rel = np.abs(outs[B, step][0] - ref).max() / np.abs(ref).max()
+      print('base size, %d songs, step %d: max rel diff to the one-song pass %.2e' % (B, step, rel))
+      assert rel < 2e-5, (B, step, rel)
