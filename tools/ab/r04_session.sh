@@ -56,6 +56,12 @@ attn)    # attention prologue (unconditional ring issue, n_keys through the vect
     one "new" X=0
   done 2>&1 | tee $OUT/${TAG}_attn_ab.log
   ;;
+multi)   # LIBS="tagA tagB ..." : the in-tree library against several tools/ab/libs/libmsd_amd_<tag>.so, alternating
+  for r in 1 2 3; do
+    for L in $LIBS; do one "$L" MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_$L.so X=0; done
+    one "new" X=0
+  done 2>&1 | tee $OUT/${TAG}_multi_ab.log
+  ;;
 final)
   timeout 1200 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
