@@ -62,6 +62,14 @@ multi)   # LIBS="tagA tagB ..." : the in-tree library against several tools/ab/l
     one "new" X=0
   done 2>&1 | tee $OUT/${TAG}_multi_ab.log
   ;;
+batch)   # BASE=<tag>: 8 songs per handle, tools/ab/libs/libmsd_amd_<BASE>.so against the in-tree library, alternating
+  OLD=$ROOT/tools/ab/libs/libmsd_amd_${BASE}.so
+  for r in 1 2 3; do
+    for L in "MSD_AMD_LIB=$OLD" "X=0"; do
+      env $L timeout 200 python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[batch 8 $L]', d['value'], d['ms_per_step'])"
+    done
+  done 2>&1 | tee $OUT/${TAG}_batch_ab.log
+  ;;
 final)
   timeout 1200 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
