@@ -91,7 +91,7 @@ def assert_fp32_class(got, ref64, ref32, what=''):
   out_dev, out_f32 = float((e_dev > 1e-2).mean()), float((e_f32 > 1e-2).mean())
   print('%s median |err| device %.2e / f32-oracle %.2e; outliers(>1e-2) device %.4f / f32-oracle %.4f; rms %.2e / %.2e'
         % (what, med_dev, med_f32, out_dev, out_f32, rms(got, ref64), rms(ref32, ref64)))
-  assert med_dev <= 2 * med_f32 + 1e-6, 'bulk error is not fp32-class'
+  assert med_dev <= 1.5 * med_f32 + 1e-6, 'bulk error is not fp32-class'   # (worst over round 4's GPU suite: 1.08)
   # Outliers: at most twice the float32 oracle's own count plus 0.3 % of the elements.  bf16x3 products carry
   # ~2^-17 relative error against float32's 2^-24, so more marginal elements flip at the clip boundary of the
   # first steps, and WHICH ones flip depends on the last bits: two builds of the same kernels whose single
@@ -108,7 +108,11 @@ def assert_fp32_class(got, ref64, ref32, what=''):
   # 27.1 / 27.5 / 30.5 % beyond 1e-4, a single half plane ('f16') 33 % and 35 %.
   # MI355X, 46 short-chain cases (profiles/r03l_tests.log): the device is within +-0.02 of the float32 oracle's fraction at
   # both thresholds (worst ratio 1.07)
-  for tau, factor, slack in ((1e-3, 1.25, 0.01), (1e-4, 1.15, 0.01)):
+  # Round 4 (the bounds of round 3, x1.25 / x1.15 + 0.01, would have passed the bfloat16-plane
+  # emulation's 6.5 % against the float32 oracle's 5.4 %): x1.10 / x1.12 + 0.005.  The bfloat16-plane figure is now
+  # outside (bound 6.44 %); the worst device case of round 4's suite (profiles/r04z_gpu_tests.log, 32 short-chain cases
+  # in both attention modes) is x1.017 / x1.070, +0.003 / +0.0185 absolute.
+  for tau, factor, slack in ((1e-3, 1.10, 0.005), (1e-4, 1.12, 0.005)):
     f_dev, f_f32 = float((e_dev > tau).mean()), float((e_f32 > tau).mean())
     print('%s elements beyond %.0e: device %.4f / f32-oracle %.4f' % (what, tau, f_dev, f_f32))
     assert f_dev <= factor * f_f32 + slack, 'too many elements beyond %.0e for float32-class arithmetic' % tau
