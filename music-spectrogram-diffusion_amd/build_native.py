@@ -4,9 +4,10 @@ The shared library is the product's compute path; it is built next to the
 sources (music-spectrogram-diffusion_amd/csrc/libmsd_amd.so) so that it travels
 with the repository snapshot to the GPU box.  Two builds of the same sources:
 libmsd_amd.so (operand planes in IEEE half: precisions 'f16x3' / 'f16') and
-libmsd_amd_bf16.so (-DMSD_PLANE_BF16=1, bfloat16 planes: 'bf16x3' / 'bf16'; csrc/common.h).  A third build,
-tools/ubench/exp/libmsd_amd_exp.so (-DMSD_EXPERIMENTS=1), adds the measured-and-rejected kernels and the environment
-switches used for same-box A/B runs; it is not part of the product (``build(experiments=True)`` / ``--experiments``).
+libmsd_amd_bf16.so (-DMSD_PLANE_BF16=1, bfloat16 planes: 'bf16x3' / 'bf16'; csrc/common.h).  The measured-and-rejected
+kernels of rounds 2 - 4 and their environment switches live OUTSIDE the product tree: tools/ubench/exp/src_r04 holds the
+sources they were built from (frozen, ABI 4) and ``build(experiments=True)`` / ``--experiments`` builds
+tools/ubench/exp/libmsd_amd_exp.so from there, if that directory exists.  Nothing in csrc/ refers to it.
 ``python -m`` cannot name this package (dash), so run:  python music-spectrogram-diffusion_amd/build_native.py
 """
 from __future__ import annotations
@@ -23,6 +24,7 @@ EXP = os.path.join(ROOT, 'tools', 'ubench', 'exp')
 LIB = os.path.join(CSRC, 'libmsd_amd.so')
 LIB_EXP = os.path.join(EXP, 'libmsd_amd_exp.so')
 LIBS = {'f16': (LIB, []), 'bf16': (os.path.join(CSRC, 'libmsd_amd_bf16.so'), ['-DMSD_PLANE_BF16=1'])}
+EXP_SRC = os.path.join(EXP, 'src_r04')   # round 4's sources with the experiments still inside
 EXP_LIBS = {'exp': (LIB_EXP, ['-DMSD_EXPERIMENTS=1'])}
 SOURCES = ['msd_api.hip']
 HEADERS = ['common.h', 'gemm_h16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
@@ -41,9 +43,10 @@ def needs_build(lib: str = LIB) -> bool:
   if not os.path.exists(lib):
     return True
   t = os.path.getmtime(lib)
-  deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + [os.path.join('..', 'build_native.py')]]
   if os.path.abspath(lib) == os.path.abspath(LIB_EXP):
-    deps += [os.path.join(EXP, f) for f in EXP_HEADERS]
+    deps = [os.path.join(EXP_SRC, f) for f in os.listdir(EXP_SRC)] + [os.path.join(EXP, f) for f in EXP_HEADERS]
+  else:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + [os.path.join('..', 'build_native.py')]]
   return any(os.path.getmtime(f) > t for f in deps)
 
 
@@ -66,8 +69,12 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
   tools/ubench/exp; returns the default one.  Each compile keeps its device listing (-save-temps, in a scratch
   directory) and runs the prefetch register check on it."""
   import tempfile
-  targets = list(LIBS.values()) + (list(EXP_LIBS.values()) if experiments else [])
-  for lib, defs in targets:
+  targets = [(lib, defs, CSRC) for lib, defs in LIBS.values()]
+  if experiments:
+    if not os.path.isdir(EXP_SRC):
+      raise RuntimeError('%s is missing: the experiments build needs the frozen round-4 sources' % EXP_SRC)
+    targets += [(lib, defs, EXP_SRC) for lib, defs in EXP_LIBS.values()]
+  for lib, defs, src in targets:
     if not force and not needs_build(lib):
       continue
     with tempfile.TemporaryDirectory(prefix='msd_build_') as tmp:
@@ -80,7 +87,7 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
       cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-save-temps',
              '-fno-gpu-rdc', '-Wno-unused-result', '-ffile-prefix-map=%s=.' % ROOT, '-ffile-prefix-map=%s=.' % tmp,
              '-cuid=msd_amd',   # the compilation-unit id (__hip_cuid_*) is otherwise a hash of the source PATH
-             '-I', CSRC] + defs + ['-o', os.path.basename(lib)] + [os.path.join(CSRC, s) for s in SOURCES]
+             '-I', src] + defs + ['-o', os.path.basename(lib)] + [os.path.join(src, s) for s in SOURCES]
       if verbose:
         print('[build_native]', ' '.join(cmd), flush=True)
       subprocess.run(cmd, check=True, cwd=tmp)

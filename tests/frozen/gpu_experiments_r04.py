@@ -11,10 +11,10 @@ import pytest
 import msd_amd
 from msd_amd import native
 from tests import helpers
-from tests.test_gpu_model import _oracle
+from tests.test_gpu_model import _oracle   # not collected by `pytest tests/` (file name); run: python -m pytest tests/frozen/gpu_experiments_r04.py -m gpu
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 EXP_LIB = os.path.join(ROOT, 'tools', 'ubench', 'exp', 'libmsd_amd_exp.so')
 
 

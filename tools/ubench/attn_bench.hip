@@ -3,7 +3,7 @@
 // MSD_ATT_ABL: 0 full; 1 fast __expf; 2 no exp at all; 3 no DMA after the prologue; 4 no PV MFMAs
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/attention.h"
+#include "exp/src_r04/attention.h"   // round-4 sources: the ablation switches live there, not in the product
 using namespace msd;
 
 template <int NP, int KS = 1>

@@ -57,6 +57,12 @@ struct AttnParams {
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
   unsigned sat_tag = 1;
   int qp = 0;                // query-side single-plane switches (attention_kernel QP bits 0 / 1), NP = 2 only
+  // Un-normalised queries (QP bit 2): q holds (x (.) gamma) . Wq WITHOUT the 1/rms of the RMSNorm in front of the
+  // projection (the hoisted cross-attention query projection, msd_api.hip); the kernel scales the logits of query
+  // row r by rstd[r] = rsqrt(sum_t q_ssq[r][t] * q_inv_d + 1e-6) -- the same algebra as the folded norms of the GEMMs.
+  const float* q_ssq = nullptr;   // [rows][q_tiles] partial sums of squares of the residual stream
+  int q_tiles = 0;                // <= 32 (multiple of 4)
+  float q_inv_d = 0.f;
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -64,6 +70,10 @@ typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
 __device__ __forceinline__ frag8 ld_frag(const h16_t* p) {
   return as_frag(*reinterpret_cast<const uint4*>(p));
 }
+
+#ifndef MSD_ATT_ABL
+#define MSD_ATT_ABL 0  // ablation switch for tools/ubench/attn_bench.hip; 0 = the product kernel
+#endif
 
 constexpr int kAttKG = 4;   // key groups (waves along the 128 keys of a stage); QB query blocks of 32 rows -> QB * 4 waves
 constexpr int kAttStageKeys = kAttKG * 32;             // 128 keys per LDS stage
@@ -87,6 +97,7 @@ constexpr int attention_smem() {
 // QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
 // O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
 // (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
+// Bit 2: the queries are un-normalised, see AttnParams::q_ssq.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
   warm_kernargs<kernarg_lines<AttnParams>()>();
@@ -97,7 +108,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       return;
     }
   }
-  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2);
+  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2), QS = (QP & 4) != 0;
 #if MSD_TIMESTAMPS
   const int ts_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   constexpr int ts_cls = QB == 1 ? 4 : 5;
@@ -166,6 +177,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   const size_t qrow = qrow0 + q_lane;
   constexpr int NPQ = Q1 ? 1 : NP;                     // planes of Q the products use
   constexpr int QOFF = NS * STAGE;
+  // QS: the partial sums of squares of this lane's query row -- 8 unconditional 16-byte loads (experiments build only)
+  f32x4 qss[QS ? 8 : 1];
+  if constexpr (QS) {
+    const int n4 = p.q_tiles >> 2;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(p.q_ssq + qrow * p.q_tiles);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qss[i] = sp[i < n4 ? i : 0];
+  }
 #pragma unroll
   for (int pl = 0; pl < NPQ; ++pl)   // wave (qb, kg) moves rows 8 kg .. 8 kg + 7 of its query block, every plane
     __builtin_amdgcn_global_load_lds(
@@ -199,6 +218,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = NEG, l_run = 0.f;
+  float q_rstd = 1.0f;
+  if constexpr (QS) {
+    const int n4 = p.q_tiles >> 2;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += (i < n4) ? (qss[i][0] + qss[i][1]) + (qss[i][2] + qss[i][3]) : 0.f;
+    q_rstd = 1.0f / sqrtf(acc * p.q_inv_d + 1e-6f);
+  }
 
   int buf = 0;
   for (int st = 0; st < nst; ++st) {
@@ -227,7 +254,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     // AFTER this wave's S^T MFMAs (below): as the first thing after the barrier the eight
     // waves' DMA instructions queue up at the CU's address unit and hold back the MFMAs
     // behind them in the in-order instruction stream.
-    const bool do_issue = st > 0 && st + NS - 1 < nst;
+    const bool do_issue = st > 0 && st + NS - 1 < nst && MSD_ATT_ABL != 3;
     int nb = buf + NS - 1;
     if (nb >= NS) nb -= NS;
     const int kb0 = (ks + st * p.ksplit) * kAttStageKeys + kg * 32;  // first key of this wave's block
@@ -257,6 +284,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) MSD_A_ISSUE(st + NS - 1, nb)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= q_rstd;   // one query per lane column: the row scale is a lane scalar
+      }
       // lane owns keys kb0 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
       float bmax = NEG;
       if (kb0 + 32 > nkeys) {  // only the last, ragged key block needs the bound
@@ -275,7 +306,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = fast_exp(s[r] - m_new);
+        pv[r] = (MSD_ATT_ABL == 2) ? (s[r] - m_new) : fast_exp(s[r] - m_new);
         psum += pv[r];
       }
       l_run = l_run * alpha + psum;
@@ -296,6 +327,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
         if (NP == 2 && !P1) pf[NP - 1][ks] = as_frag(make_uint4(wl[0], wl[1], wl[2], wl[3]));
       }
       // ---- O^T += V^T . P^T -----------------------------------------------------------
+      if (MSD_ATT_ABL == 4) { asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1])); } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         frag8 vf[NP][2];
@@ -482,6 +514,10 @@ inline hipError_t attention_prepare() {
   MSD_ATT_PREP(1, 0) MSD_ATT_PREP(2, 0)
   if constexpr (NP == 2) {
     MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3)
+#if MSD_EXPERIMENTS   // QP bit 2 (un-normalised queries) exists for the hoisted query projection only
+    MSD_ATT_PREP(1, 4) MSD_ATT_PREP(2, 4) MSD_ATT_PREP(1, 5) MSD_ATT_PREP(2, 5) MSD_ATT_PREP(1, 6) MSD_ATT_PREP(2, 6)
+    MSD_ATT_PREP(1, 7) MSD_ATT_PREP(2, 7)
+#endif
   }
 #undef MSD_ATT_PREP
   return e;
@@ -517,10 +553,16 @@ inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, 
   while ((2 << p.ksplit_log2) <= p.ksplit) ++p.ksplit_log2;
   p.ksplit = 1 << p.ksplit_log2;   // a power of two (a request for 3 runs as 2): the kernel shifts, it never divides
   if constexpr (NP == 2) {
-    switch (p.qp & 3) {
+    switch ((p.qp & 3) | (kExperiments && p.q_ssq ? 4 : 0)) {
       case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
       case 2: launch_attention_qp<NP, 2>(p, heads, segs, stream); break;
       case 3: launch_attention_qp<NP, 3>(p, heads, segs, stream); break;
+#if MSD_EXPERIMENTS
+      case 4: launch_attention_qp<NP, 4>(p, heads, segs, stream); break;
+      case 5: launch_attention_qp<NP, 5>(p, heads, segs, stream); break;
+      case 6: launch_attention_qp<NP, 6>(p, heads, segs, stream); break;
+      case 7: launch_attention_qp<NP, 7>(p, heads, segs, stream); break;
+#endif
       default: launch_attention_qp<NP, 0>(p, heads, segs, stream); break;
     }
   } else {

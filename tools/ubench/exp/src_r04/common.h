@@ -3,10 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// (The measured-and-rejected kernels of rounds 2 - 4 and their environment switches are frozen, with the sources they
-// were built from, under tools/ubench/exp/; nothing here depends on that directory.)
+// MSD_EXPERIMENTS=1 builds the A/B library of tools/ubench/exp (rejected kernels + environment switches: XCD-resident
+// chains, split-K, dual launches, batched tile variants).  The PRODUCT build (0) contains none of them and reads no
+// environment variable: what a caller may choose is in msd_config (include/msd_amd.h, ABI 4).
+#ifndef MSD_EXPERIMENTS
+#define MSD_EXPERIMENTS 0
+#endif
 
 namespace msd {
+
+constexpr bool kExperiments = MSD_EXPERIMENTS != 0;
 
 typedef uint16_t h16_t;  // raw bits of one element of an operand plane (IEEE half, or bfloat16: see below)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator

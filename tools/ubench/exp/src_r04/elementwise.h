@@ -225,6 +225,9 @@ __global__ void build_g_kernel(const float* film, const float* gamma, float* g, 
 
 // step_ptr[0] <- step_ptr[1]  (double-buffered scan index: the sampler writes the
 // next index to slot 1 while other blocks of the same launch may still read slot 0)
+#if MSD_EXPERIMENTS   // only the unfolded (separate-norm) step needs it: the folded step double-buffers the index
+__global__ void advance_step_kernel(int* step_ptr) { step_ptr[0] = step_ptr[1]; }
+#endif
 
 // scale_to_features (audio_codecs.py:176-183) on the final x0
 __global__ void unscale_kernel(const float* x0, float* out, int n, float fmin, float fmax) {

@@ -47,6 +47,11 @@ struct PrefetchTarget {
   int row_stride = 0;      // bytes between rows
   int lpr = 0;             // 128-byte lines to touch per row (<= 64)
   int lg = 0;              // log2 of the line slots per row (host: smallest power of two >= lpr)
+  // optional device-side bound, read by the prefetch wave: the cached cross-attention K / V^T of a segment are
+  // valid up to n_keys only.  dyn_mode 1: rows = min(rows, *dyn) (K: one row per key); 2: the row length is
+  // min(row bytes, *dyn * 2) (V^T: one 16-bit column per key)
+  const int* dyn = nullptr;
+  int dyn_mode = 0;
   void set(const void* p0, const void* p1, int rows_, int row_stride_, int row_bytes) {
     base[0] = static_cast<const char*>(p0); base[1] = static_cast<const char*>(p1);
     rows = rows_; row_stride = row_stride_; lpr = (row_bytes + 127) >> 7;
@@ -54,7 +59,7 @@ struct PrefetchTarget {
     while ((1 << lg) < lpr) ++lg;
   }
 };
-constexpr int kMaxPrefetchTargets = 1;   // a launch carries at most one target (more were measured: docs/history.md)
+constexpr int kMaxPrefetchTargets = 3;
 struct WeightPrefetch {
   PrefetchTarget t[kMaxPrefetchTargets];
   int n = 0;   // used slots
@@ -123,9 +128,11 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 // touches leave at the start of the launch instead of behind its main loop, which gives the lines that much more
 // time to arrive before their consumer starts.  An ended wave no longer counts at s_barrier, so the compute
 // waves' barriers are unaffected once it has gone.  One wave issues what the four compute waves issued together.
-// (-1.0 % step time same-box against the in-epilogue touches, profiles/r03f_env_ab.log)
-constexpr bool kPfWave = true;       // GEMM launches
-constexpr bool kPfWaveAttn = true;   // attention launches
+#ifndef MSD_PF_WAVE
+#define MSD_PF_WAVE 1   // 1: prefetch wave (default since round 3: -1.0 % step time same-box, profiles/r03f_env_ab.log);
+#endif                  // 0: the round-2 in-epilogue touches (kept buildable for A/B runs: -DMSD_PF_WAVE=0)
+constexpr bool kPfWave = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 2;       // GEMM launches (2: only those)
+constexpr bool kPfWaveAttn = MSD_PF_WAVE == 1 || MSD_PF_WAVE == 3;   // attention launches (3: only those)
 template <int PF>
 __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk, int nblk, const void* valid) {
   if constexpr (PF != kPfNone) {
@@ -140,7 +147,12 @@ __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk,
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
       const PrefetchTarget& t = pf.t[k];
-      const int rows = t.rows, lpr = t.lpr;
+      int rows = t.rows, lpr = t.lpr;
+      if (t.dyn_mode != 0) {
+        const int nkeys = *t.dyn;
+        if (t.dyn_mode == 1) rows = nkeys < rows ? nkeys : rows;
+        else { const int l2 = (nkeys * 2 + 127) >> 7; lpr = l2 < lpr ? l2 : lpr; }
+      }
       const int planes = t.base[1] && t.base[1] != t.base[0] ? 2 : 1;
       const int rpt = 64 >> t.lg;
       const int sub = lane >> t.lg, line = lane & ((1 << t.lg) - 1);
@@ -224,8 +236,15 @@ struct GemmParams {
       inv_nbn_x = nbn_x > 1 ? (unsigned)((0x100000000ull + (unsigned)nbn_x - 1) / (unsigned)nbn_x) : 0u;
     }
   } map;
+  int aux_half = 0;      // gemm_h16_pair.h: bytes of aux LDS per 64-row half of the tile (set by its launcher)
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck); nullptr = unchecked
   unsigned sat_tag = 1;      // what a flagged conversion stores there: kernel class + 1 (msd_api.hip)
+  // split-K launches (gemm_h16_splitk_kernel): exchange workspace [tile][dest split][src split][BM][BN/SK] fp32,
+  // one monotonic arrival counter and SK placement words per tile, an error word (bit 16+: placement, low: timeout)
+  float* sk_part = nullptr;
+  unsigned* sk_cnt = nullptr;
+  unsigned* sk_xcc = nullptr;
+  int* sk_err = nullptr;
 };
 
 // where an epilogue reports an activation that left the half-plane range
@@ -275,9 +294,59 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // applied to the per-lane SOURCE address (lane (r, c') fetches global chunk c' ^ r).
 // ----------------------------------------------------------------------------
 // One output tile (bm, bn) by the 256 threads of the calling block; `smem` = the block's dynamic LDS
-// (gemm_h16_dma_smem bytes).
-template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem) {
+// (gemm_h16_dma_smem bytes).  CP = cache policy of the loads of operands that another block of the SAME
+// kernel may have produced (A planes, residual tile, row statistics): 0 in the stand-alone kernel, 16 (sc1:
+// bypass the CU's L1, served by the XCD's L2) inside the XCD-resident chain kernels (chain.h).
+// SK > 1 (split-K, gemm_h16_splitk_kernel): this block is split `ks` of SK over the K axis of output tile `tile_id`;
+// it multiplies K-tiles [ks K/SK, (ks+1) K/SK) and, after the exchange described at the kernel, runs the epilogue
+// on columns [n0 + ks BN/SK, +BN/SK) of the tile.
+constexpr int kSplitSpinLimit = 2000000;
+
+// Persistent-layer experiment (tools/ubench/exp/chain.h, MSD_EXPERIMENTS builds): a tile may enter with the WEIGHT half
+// of its first PSN ring stages already in flight -- issued by the previous phase of the same launch behind its main
+// loop, through `hook.after_loop()` -- so that only the activation half (which depends on the previous phase) is
+// fetched behind the phase barrier.  The product's kernels run with PSN = 0 and the empty hook.
+struct NoTileHook {
+  __device__ __forceinline__ void after_loop() const {}
+};
+
+// One LDS-DMA instruction the COMPILER DOES NOT COUNT (inline asm, MI355X guide 5.7 `glds16_asm`: M0 saved, set and
+// restored inside one statement; no VGPR destination, so nothing can be reused early): 64 lanes x 16 bytes from each
+// lane's `gsrc` to LDS bytes [lds_dst + 16 lane, +16).  hipcc waits for a __builtin LDS-DMA in front of the next LDS
+// read it cannot prove disjoint -- here: the epilogue's first slab read -- which would expose exactly the latency the
+// pre-staging is meant to hide.  Completion: the consumer's own `s_waitcnt vmcnt(0)` (asm) + barrier.
+__device__ __forceinline__ void lds_dma16_uncounted(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Weight (B operand) half of ring stages [0, nst) of tile column `bn`, into the ring at LDS address `ring_lds` (the layout and the
+// per-lane source swizzle of gemm_tile's MSD_D_ISSUE); called by all four compute waves.
+template <int NP, int BM, int BN, int NS>
+__device__ __forceinline__ void gemm_prestage_b(const GemmParams& p, int bn, unsigned ring_lds, int nst) {
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = NP * (A_BYTES + B_BYTES), B_LD = BN / 32;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int r8 = lane >> 3, csrc = (lane & 7) ^ r8, n0 = bn * BN;
+  // `ring_lds`: LDS byte address of the ring (an integer: a generic -> LDS pointer cast of a pointer the compiler
+  // cannot prove non-null trips this ROCm's backend -- illegal v_cmp on src_shared_base, see aux_dma_row)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(ring_lds);
+  for (int s = 0; s < nst; ++s)
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      const h16_t* gb = p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + s * kGemmBK;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        lds_dma16_uncounted(gb + (size_t)i * 8 * p.ldb,
+                            lds0 + (unsigned)(s * STAGE_BYTES + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * i) * 128));
+    }
+}
+
+template <int NP, int BM, int BN, int NS, class Epi, int CP = 0, int PF = kPfNone, int SK = 1, int PSN = 0,
+          class Hook = NoTileHook>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem, int ks = 0,
+                                          int tile_id = 0, const Hook& hook = Hook()) {
+  static_assert(PSN == 0 || (kExperiments && SK == 1 && PSN <= NS), "pre-staged stages: experiments build only");
   // Wave layout.  2 x 2 waves of (BM/2) x (BN/2) by default.  W13 (BN == 48: the 32 x 48 tile, 256 tiles of a
   // 512 x 768 output = one per CU): three compute waves side by side, each the full 32 rows x 16 columns; wave 3
   // SHADOWS wave 2 (same fragment reads, same MFMAs, no slab store): it is there for its quarter of the DMA issue, and
@@ -286,8 +355,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // 12.5 -> 16.2 us, profiles/r04k_*.)  The K order of every output element is the same in both layouts (and in every
   // tile shape): results do not depend on the tile a GEMM runs on.
   constexpr bool W13 = BN == 48;
-  static_assert(!W13 || (NP == 2 && BM == 32), "1 x 3 wave layout: 32 x 48 tiles, two planes");
+  static_assert(!W13 || (NP == 2 && BM == 32 && SK == 1 && PSN == 0), "1 x 3 wave layout: 32 x 48 tiles, two planes");
   constexpr int WM = W13 ? BM : BM / 2, WN = W13 ? 16 : BN / 2;
+  constexpr int BNE = BN / SK;                    // columns of the tile this block's epilogue owns
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int STAGE_BYTES = NP * (A_BYTES + B_BYTES);
@@ -311,9 +381,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   const h16_t* gb[NP];
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) {
-    ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8;
+    ga[pl] = p.A[pl] + (size_t)(m0 + wave * (BM / 4) + r8) * p.lda + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
     gb[pl] = W13 ? p.B[wave >> 1] + (size_t)(n0 + (wave & 1) * (BN / 2) + r8) * p.ldb + csrc * 8   // (one plane per wave)
-                 : p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8;
+                 : p.B[pl] + (size_t)(n0 + wave * (BN / 4) + r8) * p.ldb + csrc * 8 + (SK > 1 ? ks * (p.K / SK) : 0);
   }
   const size_t a_step = (size_t)8 * p.lda, b_step = (size_t)8 * p.ldb;
 #define MSD_A_SRC(PL, I, K0) (ga[PL] + (I) * a_step + (K0))
@@ -329,7 +399,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     if constexpr (W13) {                                                                     \
       if ((Q) < NP * A_LD)                                                                   \
         __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC((Q) / A_LD, (Q) % A_LD, k0_)),   \
-            (lptr_t)(base_ + ((Q) / A_LD) * A_BYTES + (wave * (BM / 4) + 8 * ((Q) % A_LD)) * 128), 16, 0, 0); \
+            (lptr_t)(base_ + ((Q) / A_LD) * A_BYTES + (wave * (BM / 4) + 8 * ((Q) % A_LD)) * 128), 16, 0, CP); \
       else                                                                                   \
         __builtin_amdgcn_global_load_lds((gptr_t)(gb[0] + ((Q) - NP * A_LD) * b_step + k0_), \
             (lptr_t)(base_ + NP * A_BYTES + (wave >> 1) * B_BYTES +                          \
@@ -339,7 +409,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
       const int     pl_ = (Q) / AB_, r_ = (Q) % AB_;                                         \
       if (r_ < A_LD)                                                                         \
         __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl_, r_, k0_)),                  \
-            (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, 0);   \
+            (lptr_t)(base_ + pl_ * A_BYTES + (wave * (BM / 4) + 8 * r_) * 128), 16, 0, CP);  \
       else                                                                                   \
         __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl_] + (r_ - A_LD) * b_step + k0_),     \
             (lptr_t)(base_ + NP * A_BYTES + pl_ * B_BYTES + (wave * (BN / 4) + 8 * (r_ - A_LD)) * 128), 16, 0, 0); \
@@ -354,19 +424,34 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / kGemmBK;
+  const int nk = p.K / SK / kGemmBK;
   MSD_TS_BEGIN((ts_class<BM, BN>()), blockIdx.x)
   // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
+  // (stages < PSN: the weight half is already in flight -- see gemm_prestage_b -- only the activations are issued)
+#define MSD_D_ISSUE_A(KT, BUF)                                                              \
+  {                                                                                         \
+    char* base_ = smem + (BUF) * STAGE_BYTES;                                               \
+    const int k0_ = (KT) * kGemmBK;                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                       \
+      _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                      \
+          __builtin_amdgcn_global_load_lds((gptr_t)(MSD_A_SRC(pl, i, k0_)),                  \
+              (lptr_t)(base_ + pl * A_BYTES + (wave * (BM / 4) + 8 * i) * 128), 16, 0, CP); \
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s)
-    if (s < nk) MSD_D_ISSUE(s, s)
+    if (s < nk) {
+      if (s < PSN) MSD_D_ISSUE_A(s, s)
+      else MSD_D_ISSUE(s, s)
+    }
+#undef MSD_D_ISSUE_A
   // Epilogue operands (row statistics, step-indexed bias / gain rows, the residual tile) are
   // HBM-cold and used to be read by dependent global loads AFTER the K loop (+2..4 us per
   // launch).  They are DMAed into an aux LDS region behind the ring now, queued behind the
   // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
   // over-wait by these few instructions) and the final vmcnt(0) covers them.
   char* const aux = smem + NS * STAGE_BYTES;
-  epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
+  const int n0e = n0 + (SK > 1 ? ks * BNE : 0);   // first column of the epilogue's share
+  epi.template prefetch<BM, BNE, CP>(aux, m0, n0e, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   MSD_TS_STAMP(BM, BN, 1)
 
@@ -393,6 +478,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   // tile kt+1.  Before, every wave read a whole tile and then multiplied: LDS and MFMA pipes
   // alternated (64x96 tile: ~640 + ~580 clocks per K-tile) instead of overlapping.
   mfma_h16x8 fa0[NP][FM], fb0[NP][FN], fa1[NP][FM], fb1[NP][FN];
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 2   // ablation (tools/ubench): no LDS fragment reads
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa0[pl][i] = fa1[pl][i] = mfma_h16x8{1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb0[pl][j] = fb1[pl][j] = mfma_h16x8{1, 2, 3, 4, 5, 6, 7, 8};
+  }
+#undef MSD_D_READ
+#define MSD_D_READ(FA, FB, BUF, KK) {}
+#endif
   // Fine-grained issue order inside one half step: the wave's DMA and ds_read instructions
   // are spread between its MFMAs, one group per slot q: [DMA q | ds_read q | MFMAs].  Issued
   // as a block they sit in front of the MFMAs in the in-order instruction stream while the
@@ -424,6 +520,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     const int     pb_ = (pr_ == 1) ? NP - 1 : 0, pa_ = (pr_ == 2) ? NP - 1 : 0;              \
     acc[i_][j_] = MSD_MFMA_16X16X32(FB[pb_][j_], FA[pa_][i_], acc[i_][j_], 0, 0, 0); \
   }
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 1   // ablation: no MFMA
+#undef MSD_D_MFMA1
+#define MSD_D_MFMA1(FA, FB, E) { asm volatile("" ::"v"(FA[0][0]), "v"(FB[0][0])); }
+#endif
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 2   // ablation: no LDS fragment reads
+#undef MSD_D_READ1
+#define MSD_D_READ1(FA, FB, BUF, KK, Q) {}
+#endif
   // one half step: DMA of tile KT (if DO_ISSUE) into BUF_I, reads of (BUF_R, KK) into FAn/FBn,
   // MFMAs on FAc/FBc
 #define MSD_D_HALF(DO_ISSUE, KT, BUF_I, FAn, FBn, BUF_R, KK, DO_READ, FAc, FBc)              \
@@ -436,8 +540,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
       __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
   }
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 4   // ablation 4: no per-tile barrier (wrong results; timing only)
+#define MSD_D_BARRIER
+#else
 #define MSD_D_BARRIER __builtin_amdgcn_s_barrier();
+#endif
+#if defined(MSD_DMA_ABL) && MSD_DMA_ABL == 3   // ablation 3: no DMA inside the loop
+#define MSD_D_DOISSUE 0
+#else
 #define MSD_D_DOISSUE 1
+#endif
   // one K-tile: [reads of half 1 | MFMAs of half 0] wait+barrier [DMA of tile kt+NS, reads of
   // the next tile's half 0 | MFMAs of half 1]
 #define MSD_D_STEP(DO_ISSUE, VMWAIT)                                                         \
@@ -457,9 +569,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     buf = nb;                                                                                \
   }
 
-  if (nk >= NS) {
+  if (PSN == 0 && nk >= NS) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");  // tile 0 landed; NS-1 tiles in flight
   } else {
+    // (pre-staged stages: their weight DMAs were issued long ago, the prologue above issued fewer instructions per
+    // stage than the loop's counted waits assume -- everything issued so far has to land once, then the counts hold)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -495,6 +609,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_A_SRC
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
   MSD_TS_STAMP(BM, BN, 3)
+  hook.after_loop();   // (experiments: the next phase's weight tiles leave now, under this tile's epilogue)
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   auto store_slab = [&]() {
@@ -508,16 +623,24 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
                         acc[i][j][3] * kWScaleInv);   // weights are packed times kWScale (common.h)
   };
   PrefetchRegsT<PF> pf_keep;
-  // (the in-epilogue form of the weight prefetch; the product's launches carry a prefetch WAVE instead: kPfWave)
-  if constexpr (!kPfWave) prefetch_weights<PF>(p.pf, blockIdx.x, p.pf_nblk > 0 ? p.pf_nblk : (int)gridDim.x, p.B[0], pf_keep);
-  else prefetch_weights<kPfNone>(p.pf, 0, 1, nullptr, reinterpret_cast<PrefetchRegsT<kPfNone>&>(pf_keep));
-  store_slab();
-  epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
-  __syncthreads();
-  MSD_TS_STAMP(BM, BN, 4)
-  epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
-  MSD_TS_STAMP(BM, BN, 5)
-  MSD_TS_END((ts_class<BM, BN>()), blockIdx.x, gridDim.x)
+  if constexpr (SK == 1) {
+    // the epilogue below (2 .. 5 us) hides the prefetch of a later launch's weights
+    if constexpr (!kPfWave) prefetch_weights<PF>(p.pf, blockIdx.x, p.pf_nblk > 0 ? p.pf_nblk : (int)gridDim.x, p.B[0], pf_keep);
+    else prefetch_weights<kPfNone>(p.pf, 0, 1, nullptr, reinterpret_cast<PrefetchRegsT<kPfNone>&>(pf_keep));
+    store_slab();
+    epi.template stats<BM, LDS_LD>(slab, m0, tid, aux);   // row statistics next to the slab stores: one barrier
+    __syncthreads();
+    MSD_TS_STAMP(BM, BN, 4)
+    epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
+    MSD_TS_STAMP(BM, BN, 5)
+    MSD_TS_END((ts_class<BM, BN>()), blockIdx.x, gridDim.x)
+  } else {
+#if MSD_EXPERIMENTS
+#include "../gemm_splitk_exchange.inc"
+#else
+    static_assert(SK == 1, "split-K is an experiments-build kernel (tools/ubench/exp)");
+#endif
+  }
   prefetch_done(pf_keep);
 }
 
@@ -553,7 +676,7 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(Gemm
     bm = (tt - q * tm.nbm_x) * RX + xr; bn = q * CX + xc;
   }
   if (bn >= tm.nbn || bm >= tm.nbm) return;
-  gemm_tile<NP, BM, BN, NS, Epi, PF>(p, epi, bm, bn, smem);
+  gemm_tile<NP, BM, BN, NS, Epi, 0, PF>(p, epi, bm, bn, smem);
 }
 
 // ----------------------------------------------------------------------------
@@ -605,7 +728,8 @@ constexpr int kAuxMaxTiles = 32;  // ssq partials per row the aux region is size
 // Does this tile have an aux LDS region?  Every kernel of the library does (gemm_tile and the batched variants pass
 // one), so the answer is a compile-time `true` -- NOT a test of the pointer: a null test of a generic pointer that
 // points into LDS is what this ROCm's backend turns into an illegal v_cmp on src_shared_base once a tile loop keeps it
-// from folding the test away (which instantiation fails moves with every unrelated edit).  tools/ubench/gemm_h16_regstaged.h, the one caller without aux rows, defines MSD_EPI_AUX_OPTIONAL.
+// from folding the test away (the chain kernels of tools/ubench/exp hit it; which instantiation fails moves with every
+// unrelated edit).  tools/ubench/gemm_h16_regstaged.h, the one caller without aux rows, defines MSD_EPI_AUX_OPTIONAL.
 #ifndef MSD_EPI_AUX_OPTIONAL
 #define MSD_EPI_AUX_OPTIONAL 0
 #endif
@@ -644,12 +768,13 @@ __device__ __forceinline__ int scan_index(const int* p) {
 // LDS-DMA of `bytes` contiguous, 16-byte aligned global bytes to dst (linear), one 1 KiB
 // instruction per wave round-robin.  Lanes past the end re-fetch the last chunk; their LDS
 // writes land in the padding (dst needs round_up(bytes, 1024) bytes).
+template <int CP = 0>
 __device__ __forceinline__ void aux_dma_linear(const void* g, char* dst, int bytes, int wave, int lane) {
   const int n_instr = (bytes + 1023) >> 10;
   for (int i = wave; i < n_instr; i += 4) {
     int off = i * 1024 + lane * 16;
     off = off < bytes - 16 ? off : bytes - 16;
-    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), lds_ptr_of(dst + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((aux_gptr_t)((const char*)g + off), lds_ptr_of(dst + i * 1024), 16, 0, CP);
   }
 }
 
@@ -668,10 +793,10 @@ constexpr int rowscale_aux_bytes() { return BM * kAuxMaxTiles * 4 + 1024; }
 template <int BM>
 __host__ __device__ __forceinline__ int rowscale_ssq_bytes(int tiles) { return (BM * tiles * 4 + 1023) & ~1023; }
 
-template <int BM, int BN>
+template <int BM, int BN, int CP = 0>
 __device__ __forceinline__ void rowscale_prefetch(const RowScale& r, char* aux, int m0, int n0, int wave, int lane) {
   if (!r.ssq) return;
-  aux_dma_linear(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
+  aux_dma_linear<CP>(r.ssq + (size_t)m0 * r.tiles, aux, BM * r.tiles * 4, wave, lane);
   if (r.bias && wave == 3)
     aux_dma_row(r.bias + (size_t)scan_index(r.step_ptr) * r.bias_step_stride + n0, aux + rowscale_ssq_bytes<BM>(r.tiles), BN * 4, lane);
 }
@@ -781,9 +906,9 @@ struct EpiStoreH16 {
   int ldc;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -819,9 +944,9 @@ struct EpiQKV {
   int ld_qk, v_start, seg_len, vt_ld, vt_rows;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -881,7 +1006,7 @@ struct EpiResidual {
   float* x;
   int ldx;
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
@@ -916,12 +1041,17 @@ struct EpiResidualNorm {
   const float* g_hi; int g_hi_stride;
   int split_row;
   const int* step_ptr;
-  // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB]
+  // optional second plane pair: y2 = x (.) g2 for rows < y2_rows (g2 is NOT step-indexed) -- the plain-gamma input
+  // of the next layer's hoisted cross-attention query projection
+  h16_t* y2[2] = {nullptr, nullptr};
+  const float* g2 = nullptr;
+  int y2_rows = 0;
+  // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB][g2 slice, 1 KiB]
   template <int BN> static constexpr bool narrow() { return BN == 32 || BN == 48; }
-  template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 2048 : 0; }
+  template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 3072 : 0; }
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
     if (!narrow<BN>()) return;
     // the residual tile, row-major: 16-byte chunk id = 64 i + lane is chunk id % (BN/4) of row id / (BN/4)
@@ -931,11 +1061,12 @@ struct EpiResidualNorm {
     for (int i = wave; i < BM * CPR / 64; i += 4) {
       const int id = i * 64 + lane, r = id / CPR, ch = id % CPR;
       __builtin_amdgcn_global_load_lds((aux_gptr_t)(x + (size_t)(m0 + r) * ldx + n0 + ch * 4),
-                                       lds_ptr_of(aux + i * 1024), 16, 0, 0);
+                                       lds_ptr_of(aux + i * 1024), 16, 0, CP);
     }
     // (only the two waves that fetch a step-indexed row read the scan index)
     if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)scan_index(step_ptr) * g_lo_stride + n0, aux + BM * BN * 4, BN * 4, lane);
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)scan_index(step_ptr) * g_hi_stride + n0, aux + BM * BN * 4 + 1024, BN * 4, lane);
+    if (kExperiments && g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * BN * 4 + 2048, BN * 4, lane);
   }
   // 32 x 48 tiles: 8 lanes per row, 6 of them with 8 columns each; ONE partial sum of squares per row and tile, in
   // slot n0 / 48 of the row's `tiles` (= D / 32) slots -- the D / 48 slots a row gets this way are fewer than `tiles`,
@@ -973,6 +1104,13 @@ struct EpiResidualNorm {
     if (c == 0) ssq[(size_t)row * tiles + slot] = sq;
     if (c == 6 && used + slot < tiles) ssq[(size_t)row * tiles + used + slot] = 0.f;
     RangeCheck rc;
+    if (kExperiments && g2 != nullptr && act && row < y2_rows) {
+      lds_cf32x4 gc = (lds_cf32x4)(aux + BM * BN * 4 + 2048);
+      const f32x4 c0 = gc[n / 4], c1 = gc[n / 4 + 1];
+      const float w[8] = {v[0] * c0[0], v[1] * c0[1], v[2] * c0[2], v[3] * c0[3],
+                          v[4] * c1[0], v[5] * c1[1], v[6] * c1[2], v[7] * c1[3]};
+      store_h16x8<NP>(y2, (size_t)row * ldx + col, w, rc);
+    }
     const bool lo_rows = row < split_row;
     if (act && (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr))) {
       const f32x4 g0 = lo_rows ? gl[n / 4] : gh[n / 4], g1 = lo_rows ? gl[n / 4 + 1] : gh[n / 4 + 1];
@@ -993,7 +1131,7 @@ struct EpiResidualNorm {
     const int step = pre ? 0 : *step_ptr;
     RangeCheck rc;
     // one tile-element group (8 columns of one row); LX / LG fetch the residual and the gain
-    auto body = [&](int item, auto LX, auto LG) {
+    auto body = [&](int item, auto LX, auto LG, auto LG2) {
       const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;   // BN/8 consecutive lanes share a row
       float v[8];
       tile_row8<LD>(s0, m, n, v);
@@ -1011,6 +1149,13 @@ struct EpiResidualNorm {
       sq += __shfl_xor(sq, 1, 64);   // 4 consecutive lanes = one 32-column group of one row
       sq += __shfl_xor(sq, 2, 64);
       if ((item & 3) == 0) ssq[(size_t)row * tiles + col / 32] = sq;
+      if (kExperiments && g2 != nullptr && row < y2_rows) {
+        float4 g0, g1;
+        LG2(n, col, g0, g1);
+        const float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w,
+                            v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
+        store_h16x8<NP>(y2, (size_t)row * ldx + col, w, rc);
+      }
       const bool lo_rows = row < split_row;
       if (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr)) {
         float4 g0, g1;
@@ -1025,13 +1170,15 @@ struct EpiResidualNorm {
       auto f4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
       lds_cf32x4 xs = (lds_cf32x4)(aux);
       lds_cf32x4 gl = (lds_cf32x4)(aux + BM * 128), gh = (lds_cf32x4)(aux + BM * 128 + 1024);
+      lds_cf32x4 gc = (lds_cf32x4)(aux + BM * 128 + 2048);
       for (int item = tid; item < BM * BN / 8; item += 256)
         body(item,
              [&](int m, int n, float4*, float4& a, float4& b) { a = f4(xs[(m * BN + n) / 4]); b = f4(xs[(m * BN + n) / 4 + 1]); },
              [&](bool lo_rows, int n, int, float4& g0, float4& g1) {
                g0 = f4(lo_rows ? gl[n / 4] : gh[n / 4]);
                g1 = f4(lo_rows ? gl[n / 4 + 1] : gh[n / 4 + 1]);
-             });
+             },
+             [&](int n, int, float4& g0, float4& g1) { g0 = f4(gc[n / 4]); g1 = f4(gc[n / 4 + 1]); });
     } else {
       // The batched path's 128 x 96 tiles come here (no aux copy of the residual tile: it would not fit behind the
       // ring).  Round 3's form loaded an item's residual and gain rows INSIDE the item loop: a rolled loop whose every
@@ -1065,7 +1212,11 @@ struct EpiResidualNorm {
         if (ITEMS % 256 == 0 || item < ITEMS)
           body(item,
                [&](int, int, float4*, float4& a, float4& b2) { a = f4(xa[it]); b2 = f4(xb[it]); },
-               [&](bool, int, int, float4& g0, float4& g1) { g0 = f4(ga[it]); g1 = f4(gb[it]); });
+               [&](bool, int, int, float4& g0, float4& g1) { g0 = f4(ga[it]); g1 = f4(gb[it]); },
+               [&](int, int col, float4& g0, float4& g1) {
+                 g0 = *reinterpret_cast<const float4*>(g2 + col);
+                 g1 = *reinterpret_cast<const float4*>(g2 + col + 4);
+               });
       }
     }
     rc.commit(sf.p, sf.tag);
@@ -1088,8 +1239,11 @@ struct EpiInProj {
   const float* g; int g_stride;
   const int* step_ptr;
   int* step_copy = nullptr;   // = step_ptr when the sampler follows in the same step
+  // optional: y2 = x (.) g2 for the first pass's rows (layer 0's hoisted cross-attention query projection)
+  h16_t* y2[2] = {nullptr, nullptr};
+  const float* g2 = nullptr;
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char*, int, int, int, int) const {}
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
@@ -1122,6 +1276,12 @@ struct EpiInProj {
       const float4 g1 = *reinterpret_cast<const float4*>(gs + col + 4);
       float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w,
                     v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
+      if (kExperiments && g2 != nullptr) {   // pass 0 = the conditional rows
+        const float4 c0 = *reinterpret_cast<const float4*>(g2 + col), c1 = *reinterpret_cast<const float4*>(g2 + col + 4);
+        const float u[8] = {v[0] * c0.x, v[1] * c0.y, v[2] * c0.z, v[3] * c0.w,
+                            v[4] * c1.x, v[5] * c1.y, v[6] * c1.z, v[7] * c1.w};
+        store_h16x8<NP>(y2, (size_t)row * ldx + col, u, rc);
+      }
       for (int ps = 0; ps < passes; ++ps) {
         const size_t r = (size_t)ps * pass_rows + row;
         float4* px = reinterpret_cast<float4*>(x + r * ldx + col);
@@ -1141,9 +1301,9 @@ struct EpiStoreF32 {
   int ldc;
   RowScale rsc;
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -1179,9 +1339,9 @@ struct EpiGeglu {
   int ldc;  // = F
   RowScale rsc;  // bias table is indexed by PACKED column
   template <int BM, int BN> static constexpr int aux_bytes() { return rowscale_aux_bytes<BM>(); }
-  template <int BM, int BN>
+  template <int BM, int BN, int CP = 0>
   __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
-    rowscale_prefetch<BM, BN>(rsc, aux, m0, n0, wave, lane);
+    rowscale_prefetch<BM, BN, CP>(rsc, aux, m0, n0, wave, lane);
   }
   template <int BM, int LD>
   __device__ void stats(float* s0, int m0, int tid, const char* aux) const {
@@ -1236,8 +1396,12 @@ inline hipError_t gemm_h16_dma_prepare_one() {
 template <int NP, int BM, int BN, int NS, class Epi>
 inline hipError_t gemm_h16_dma_prepare() {
   hipError_t e = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 0>(), r;
-  if constexpr (NP == 2 && epi_may_prefetch<Epi>::value) {   // the single-plane mode never prefetches
+  if constexpr (NP == 2 && (kExperiments || epi_may_prefetch<Epi>::value)) {   // the single-plane mode never prefetches
     if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 1>()) != hipSuccess) e = r;
+#if MSD_EXPERIMENTS          // the product carries at most ONE prefetch target per launch
+    if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 2>()) != hipSuccess) e = r;
+    if ((r = gemm_h16_dma_prepare_one<NP, BM, BN, NS, Epi, 3>()) != hipSuccess) e = r;
+#endif
   }
   return e;
 }
@@ -1255,7 +1419,11 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p_in, const Epi& epi, hi
 #define MSD_LAUNCH_PF(PF_) \
   hipLaunchKernelGGL((gemm_h16_dma_kernel<NP, BM, BN, NS, Epi, PF_>), dim3(grid), dim3(256 + pf_threads(PF_)), smem, stream, p, epi)
   const int npf = NP == 2 ? prefetch_kind(p.pf) : 0;
-  if constexpr (NP == 2 && epi_may_prefetch<Epi>::value) {
+  if constexpr (NP == 2 && (kExperiments || epi_may_prefetch<Epi>::value)) {
+#if MSD_EXPERIMENTS
+    if (npf == 2) { MSD_LAUNCH_PF(2); return hipGetLastError(); }
+    if (npf >= 3) { MSD_LAUNCH_PF(3); return hipGetLastError(); }
+#endif
     if (npf >= 1) MSD_LAUNCH_PF(1);   // product: the first target only
     else MSD_LAUNCH_PF(0);
   } else {
@@ -1267,6 +1435,9 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p_in, const Epi& epi, hi
 
 }  // namespace msd
 
+#if MSD_EXPERIMENTS
+#include "../gemm_h16_exp.h"
+#endif
 
 #if MSD_TIMESTAMPS   // debug builds only (tools/diag/phase_times.py); the product library has no such symbol
 extern "C" int msd_debug_timestamps(unsigned long long* host_out) {   // [kTsClasses][kTsBlocks][kTsFields]

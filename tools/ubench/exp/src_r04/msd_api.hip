@@ -14,12 +14,18 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/msd_amd.h"
+#include "msd_amd.h"   // (frozen with these sources: ABI 4)
 #include "attention.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_h16.h"
 #include "gemm_f32.h"
+#if MSD_EXPERIMENTS   // rejected kernels + environment switches of the A/B build (tools/ubench/exp/README.md); never in the product
+#include "../chain.h"
+#include "../gemm_h16_pair.h"
+#include "../gemm_h16_wide.h"
+#include "../gemm_h16_ls.h"
+#endif
 
 using namespace msd;
 
@@ -35,11 +41,11 @@ constexpr int kDefaultQPlanes = 2, kDefaultPPlanes = 2;
 
 enum KClass { KC_NORM = 0, KC_GEMM_QKV, KC_ATTN_SELF, KC_GEMM_ATTN_OUT, KC_GEMM_CROSS_Q,
               KC_ATTN_CROSS, KC_GEMM_CROSS_OUT, KC_GEMM_MLP_IN, KC_GEMM_MLP_OUT,
-              KC_FINAL_PROJ, KC_SAMPLER, KC_IN_PROJ, KC_COUNT };
+              KC_FINAL_PROJ, KC_SAMPLER, KC_IN_PROJ, KC_CHAIN_MLP, KC_COUNT };
 const char* const kClassNames[KC_COUNT + 1] = {
     "rmsnorm_film", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
     "gemm_cross_out", "gemm_mlp_in_geglu", "gemm_mlp_out", "final_proj_f32", "sampler_step",
-    "in_proj_f32", nullptr};
+    "in_proj_f32", "chain_mlp_qkv", nullptr};
 
 struct Planes {
   h16_t* p[2] = {nullptr, nullptr};
@@ -75,6 +81,10 @@ struct DecLayerW {
   Planes wq_cross[2];   // [J, D]
   Planes wkv_cross[2];  // [2J, D] (k|v)
   Planes wo_cross[2];   // [D, J]
+#if MSD_EXPERIMENTS
+  // hoisted query projection of module 0 (decoder_layers): W^T of Wo_self . diag(gamma_cross) . Wq, [J, J]
+  Planes w2;
+#endif
   MlpW mlp;
 };
 struct EncoderW {
@@ -131,6 +141,7 @@ struct msd_model {
   float* ssq = nullptr;        // [rows][D/64] partial sums of squares of x
   float *att_part_o = nullptr, *att_part_ml = nullptr;  // key-split attention partials
   int cross_ksplit = 1;        // key split of the cross-attention at batch 1 (allocation bound)
+  bool cross_ksplit_fixed = false;   // experiments build, MSD_CROSS_KSPLIT given: use it at every batch size
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
@@ -162,6 +173,34 @@ struct msd_model {
   // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
   // 2 = the softmax weights enter P.V as one plane); from msd_config.attn_q_planes / attn_p_planes, DESIGN.md 3
   int att_qp_self = 0, att_qp_cross = 0;
+#if MSD_EXPERIMENTS
+  // ---- A/B switches of the experiments build, read from the environment by exp_read_env() (docs/history.md) ----
+  bool dual_chain = false;     // CFG passes as two concurrent graph branches (MSD_DUAL_CHAIN)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool fold_norm = true;       // MSD_FOLD_NORM=0: separate RMSNorm kernels
+  bool chain_mlp = false;      // XCD-resident chain MLP-in -> MLP-out -> next QKV (chain.h; MSD_CHAIN)
+  int chain_mode = 0;          // MSD_CHAIN's value: 1 = round 2's chain, 2 = with pre-staged weights (round 4)
+  bool pf_kv = false;          // QKV launch also warms the layer's cached cross-attention K / V^T (MSD_PF_KV)
+  bool big_pair = false, big_wide = false, big_ls = false;   // batched tile variants (MSD_BIG_PAIR / _WIDE / _LS)
+  bool tile48 = true;          // MSD_TILE48=0: the N = D projections stay on 32 x 32 / 64 x 32 tiles (round 3's shapes)
+  unsigned* d_bar = nullptr;   // [8][kBarStride] XCD barrier counters
+  int* d_chain_err = nullptr;  // raised by a timed-out XCD barrier
+  bool hoist_q = false;        // hoisted cross-attention query projection (MSD_HOIST_Q)
+  Planes yc;                   // x (.) gamma_cross of the layer about to run, conditional rows [Bmax * T, D]
+  float* qpart = nullptr;      // (x0 (.) gamma_cross) . Wq of the layer, fp32 [Bmax * T, J]
+  bool splitk = false;         // split-K MLP output projection (MSD_SPLITK)
+  int splitk_min_k = 2048;
+  float* sk_part = nullptr;    // exchange workspace
+  unsigned* sk_cnt = nullptr;  // [tiles] arrival counters
+  unsigned* sk_xcc = nullptr;  // [tiles][SK] placement words
+  int* d_sk_err = nullptr;
+  size_t sk_tiles = 0;
+  int xcd_rows = 2, xcd_walk_n = 1;   // MSD_XCD_ROWS / MSD_XCD_WALK_N
+  int big_m = 2048;                   // MSD_BIG_M
+#else
+  static constexpr bool fold_norm = true;   // the product always folds RMSNorm + FiLM into the GEMM epilogues
+#endif
   unsigned* d_sat = nullptr;   // half-plane range flag: kernel class + 1 of a conversion that saw |x| > 65504 (common.h RangeCheck)
   unsigned* h_sat = nullptr;   // pinned host copy, read after the stream sync that ends msd_encode / msd_sample
   hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) NULL stream
@@ -235,6 +274,42 @@ int check_range(msd_model* m, hipStream_t s, const char* what) {
               "result of this call is INVALID.  Use precision 'bf16x3' (libmsd_amd_bf16.so: bfloat16 planes keep "
               "float32's exponent range at twice the rounding error)", what, (double)kPlaneMax, cls);
 }
+
+
+// In-kernel synchronisation words exist only in the experiments build (split-K arrival counters, chain barriers:
+// fresh for every msd_* call that launches decoder steps, read back behind the call's final stream sync, so that a
+// timed-out wait or a block group that was not placed on one XCD fails THAT call).  The product's kernels never wait
+// for another block of their own launch.
+#if MSD_EXPERIMENTS
+int reset_sync_words(msd_model* m, hipStream_t s) {
+  if (m->sk_cnt) {
+    HIP_TRY(m, hipMemsetAsync(m->sk_cnt, 0, sizeof(unsigned) * m->sk_tiles, s));
+    HIP_TRY(m, hipMemsetAsync(m->sk_xcc, 0, sizeof(unsigned) * m->sk_tiles * 4, s));
+  }
+  HIP_TRY(m, hipMemsetAsync(m->d_sk_err, 0, sizeof(int), s));
+  if (m->chain_mlp) {   // the arrival index of chain.h's barrier would wrap after ~1e8 barriers
+    HIP_TRY(m, hipMemsetAsync(m->d_bar, 0, sizeof(unsigned) * 8 * kBarStride, s));
+    HIP_TRY(m, hipMemsetAsync(m->d_chain_err, 0, sizeof(int), s));
+  }
+  return MSD_OK;
+}
+int check_sync_words(msd_model* m, const char* what) {   // call after the stream has been synchronised
+  int bad[2] = {0, 0};
+  HIP_TRY(m, hipMemcpy(&bad[0], m->d_sk_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (m->chain_mlp) HIP_TRY(m, hipMemcpy(&bad[1], m->d_chain_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad[0])
+    return fail(m, MSD_ERR_HIP, "%s: the split-K MLP output projection reported %d barrier timeouts and %d block groups "
+                "spread over several XCDs; the result of this call is invalid (MSD_SPLITK=0 selects the plain kernel)",
+                what, bad[0] & 0xffff, bad[0] >> 16);
+  if (bad[1])
+    return fail(m, MSD_ERR_HIP, "%s: an XCD-resident chain kernel reported %d barrier timeouts and %d blocks that were not on "
+                "the XCD of their slot; the result of this call is invalid (MSD_CHAIN=0)", what, bad[1] & 0xffff, bad[1] >> 16);
+  return MSD_OK;
+}
+#else
+inline int reset_sync_words(msd_model*, hipStream_t) { return MSD_OK; }
+inline int check_sync_words(msd_model*, const char*) { return MSD_OK; }
+#endif
 
 void add_weight(msd_model* m, const std::string& name, int64_t a, int64_t b = -1) {
   Weight w;
@@ -353,7 +428,20 @@ enum TileKind { TK_NARROW = 0, TK_TALL = 1, TK_QKV = 2, TK_MLP_IN = 3, TK_SQUARE
 // better than 1 x 8 everywhere.
 void set_xcd_grid(const msd_model* m, GemmParams& p, int kc, int M, int BM) {
   int rx = 2, walk_n = 1;
+#if MSD_EXPERIMENTS
+  rx = m->xcd_rows; walk_n = m->xcd_walk_n;
+  // per-class override for A/B runs: MSD_XCD_<class name, upper case>="rows,walk", e.g. MSD_XCD_GEMM_QKV=1,0
+  char name[64] = "MSD_XCD_";
+  size_t n = 8;
+  for (const char* q = kClassNames[kc]; *q && n + 1 < sizeof(name); ++q) name[n++] = (char)toupper(*q);
+  name[n] = 0;
+  if (const char* v = getenv(name)) {
+    int a = 0, b = 0;
+    if (sscanf(v, "%d,%d", &a, &b) == 2 && a > 0) { rx = a; walk_n = b; }
+  }
+#else
   (void)m; (void)kc;
+#endif
   p.xcd_rows = (rx == 1 || rx == 2 || rx == 4 || rx == 8) && ((M / BM) % rx == 0) ? rx : 1;
   p.xcd_walk_n = walk_n;
 }
@@ -371,6 +459,46 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.end(kc);
 }
 
+#if MSD_EXPERIMENTS
+// the same launch on the batched path's co-resident K = 32 tiles (gemm_h16_pair.h)
+template <int NP, int BM, int BN, class Epi>
+void gemm_t_pair(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(c.m, p, kc, M, BM);
+  hipError_t e = launch_gemm_h16_pair<NP, BM, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+// ... and on the 256 x 128 eight-wave tiles (gemm_h16_wide.h)
+template <int NP, int BN, class Epi>
+void gemm_t_wide(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(c.m, p, kc, M, 256);
+  hipError_t e = launch_gemm_h16_wide<NP, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+// ... and on the 256 x 128 tiles with loader waves (gemm_h16_ls.h)
+template <int NP, int BN, class Epi>
+void gemm_t_ls(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi,
+               const WeightPrefetch* pf) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(c.m, p, kc, M, 256);
+  hipError_t e = launch_gemm_h16_ls<NP, BN, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+#endif   // MSD_EXPERIMENTS
 
 constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
 
@@ -386,7 +514,14 @@ inline long tile_cost(int M, int N, int BM, int BN) {
 // Batched songs (M = passes * B * T >= big_m_threshold() = 2048): every CU has several tiles anyway, so the tiles
 // grow to 128 x 96/128 (2-deep ring, 128 KiB) -- half the L2->LDS re-reads per MAC
 // (tools/ubench/gemm_bench_big.hip, M = 4096: QKV 85 -> 61 us, MLP-in 114 -> 95, MLP-out 68 -> 48).
+#if MSD_EXPERIMENTS
+inline int big_m_threshold() {   // rows from which the 128-row tiles are used (MSD_BIG_M overrides)
+  static const int v = [] { const char* e = getenv("MSD_BIG_M"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+  return v;
+}
+#else
 constexpr int big_m_threshold() { return 2048; }   // rows from which the 128-row tiles are used
+#endif
 
 // epilogues that run on 32 x 48 tiles (gemm_h16.h EpiResidualNorm::run48)
 template <class Epi> struct epi_takes_48 : std::false_type {};
@@ -432,7 +567,11 @@ TileShape pick_tile(int M, int N, int align, bool wide48 = false, int K = 0) {
 template <int NP, int TK, class Epi>
 void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K,
           const Epi& epi, int align = 0, const WeightPrefetch* pf = nullptr) {
+#if MSD_EXPERIMENTS
+  const bool wide48 = epi_takes_48<Epi>::value && c.m->tile48;
+#else
   constexpr bool wide48 = epi_takes_48<Epi>::value;
+#endif
   const TileShape t = pick_tile<NP, TK>(M, N, align, wide48, K);
 #define MSD_GO(BM_, BN_, NS_) return gemm_t<NP, BM_, BN_, NS_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf)
 // Batched songs: 128-row tiles, 2-deep ring of K = 64 tiles.  A 4-deep ring of K = 32 tiles (64-byte rows, its own
@@ -440,7 +579,15 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 // the batched test and measured 10 % SLOWER end to end at 8 and 16 songs (profiles/r03m_k32_ab.log: 465 vs 516 and
 // 498 vs 550 mel-frames/s; gated MLP input 1.34 vs 1.13 ms per step): twice the barriers per K and one wave per SIMD
 // at 340 registers cost more than the deeper ring hides.  Not in the product build.
+#if MSD_EXPERIMENTS
+#define MSD_GO_BIG(BM_, BN_)                                                                                          \
+  {                                                                                                                   \
+    if (c.m->big_pair && K % kPairBK == 0) return gemm_t_pair<NP, BM_, BN_, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi); \
+    MSD_GO(BM_, BN_, 2);                                                                                              \
+  }
+#else
 #define MSD_GO_BIG(BM_, BN_) MSD_GO(BM_, BN_, 2);
+#endif
   if constexpr (TK == TK_QKV) {
     if constexpr (NP == 2) {
       if (t.bm == 128) MSD_GO_BIG(128, 96)
@@ -449,6 +596,12 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     MSD_GO(64, 64, wide_ns(NP));
   } else if constexpr (TK == TK_MLP_IN) {
     if constexpr (NP == 2) {
+#if MSD_EXPERIMENTS
+      if (t.bm == 128 && c.m->big_ls && gemm_h16_ls_fits<128>(M, N, K))
+        return gemm_t_ls<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi, pf);
+      if (t.bm == 128 && c.m->big_wide && gemm_h16_wide_fits<128>(M, N, K))
+        return gemm_t_wide<NP, 128, Epi>(c, kc, a, lda, b, ldb, M, N, K, epi);
+#endif
       if (t.bm == 128) MSD_GO_BIG(128, 128)
       if (t.bn == 128) MSD_GO(64, 128, 3);
     }
@@ -469,6 +622,31 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
 #undef MSD_GO
 }
 
+#if MSD_EXPERIMENTS
+// The MLP output projection as a 4-way split-K launch on 64 x 128 tiles (gemm_h16.h): only where all blocks of the
+// launch are resident at once (they wait for each other) and K is long enough to pay for the exchange.
+constexpr int kSkBM = 64, kSkBN = 128, kSkNS = 3, kSkSplit = 4;
+inline bool splitk_fits(const msd_model* m, int NP, int M, int N, int K) {
+  if (!m->splitk || NP != 2 || !m->sk_part || M % kSkBM || N % kSkBN || K % (kSkSplit * kGemmBK) || K < m->splitk_min_k) return false;
+  const int tiles = (M / kSkBM) * (N / kSkBN);
+  return tiles * kSkSplit <= m->cus && (size_t)tiles <= m->sk_tiles && splitk_xcd_rows(M / kSkBM, N / kSkBN) > 0 &&
+         M < big_m_threshold();
+}
+template <int NP, class Epi>
+void gemm_splitk(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, const Epi& epi,
+                 const WeightPrefetch* pf) {
+  c.begin(kc);
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  p.xcd_rows = splitk_xcd_rows(M / kSkBM, N / kSkBN);
+  p.sk_part = c.m->sk_part; p.sk_cnt = c.m->sk_cnt; p.sk_xcc = c.m->sk_xcc; p.sk_err = c.m->d_sk_err;
+  hipError_t e = launch_gemm_h16_splitk<NP, kSkBM, kSkBN, kSkNS, kSkSplit, Epi>(p, epi, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
+
+#endif   // MSD_EXPERIMENTS
 
 // Prefetch target = the packed W^T planes [N, K] of a later GEMM (gemm_h16.h PrefetchTarget)
 template <int NP>
@@ -517,6 +695,11 @@ void norm(Ctx& c, const float* x, const float* gamma, int rows, int D, const flo
   c.begin(KC_NORM);
   const int vpl = (D + 255) / 256;
 #define NORM_LAUNCH(OUT, VPL) hipLaunchKernelGGL((rmsnorm_film_kernel<OUT, VPL>), grid, block, 0, c.s, p)
+#if MSD_EXPERIMENTS   // fp32 output: the unfolded decoder's final norm only
+  if (out_f32) {
+    if (vpl <= 1) NORM_LAUNCH(2, 1); else if (vpl <= 2) NORM_LAUNCH(2, 2); else if (vpl <= 3) NORM_LAUNCH(2, 3); else NORM_LAUNCH(2, 4);
+  } else
+#endif
   if (NP == 2) {
     if (vpl <= 1) NORM_LAUNCH(1, 1); else if (vpl <= 2) NORM_LAUNCH(1, 2); else if (vpl <= 3) NORM_LAUNCH(1, 3); else NORM_LAUNCH(1, 4);
   } else {
@@ -530,7 +713,8 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1,
+               const float* q_ssq = nullptr) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -543,6 +727,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   p.total_rows = q_rows_per_seg * segs;
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  if (q_ssq) { p.q_ssq = q_ssq; p.q_tiles = c.m->D / kNarrowTile; p.q_inv_d = 1.0f / (float)c.m->D; }
   p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
@@ -910,29 +1095,103 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
   return check_range(m, s, "msd_encode");   // synchronises
 }
 
+#if MSD_EXPERIMENTS
+// ---- one decoder evaluation (network.py:360-457) on rows [0, P*batch*T) ----------
+// pass 0 is conditional iff `cond0`; pass 1 (if P == 2) is the unconditional CFG pass.
+// Unfolded variant: one RMSNorm(+FiLM) kernel in front of every projection.
+template <int NP>
+void decoder_layers_unfolded(Ctx& c, int batch, int P, bool cond0) {
+  msd_model* m = c.m;
+  const int D = m->D, J = m->J, F = m->F, T = m->T;
+  const int BT = batch * T, M = P * BT;
+  const int slots = 2 * m->Ld;
+  for (int l = 0; l < m->Ld; ++l) {
+    const DecLayerW& w = m->dec[l];
+    norm<NP>(c, m->x, w.ln_self, M, D, m->d_film, slots, 2 * l, &m->h, nullptr);
+    EpiQKV<NP> eq;
+    eq.qk[0] = m->qk.p[0]; eq.qk[1] = m->qk.p[NP - 1];
+    eq.vt[0] = m->vt.p[0]; eq.vt[1] = m->vt.p[NP - 1];
+    eq.ld_qk = 2 * J; eq.v_start = 2 * J; eq.seg_len = T; eq.vt_ld = T; eq.vt_rows = J;
+    gemm<NP, TK_QKV>(c, KC_GEMM_QKV, m->h, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start);
+    const h16_t* kp[2] = {m->qk.p[0] + J, m->qk.p[NP - 1] + J};
+    attention<NP>(c, KC_ATTN_SELF, m->qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, m->vt, T,
+                  (size_t)J * T, m->ao, J, m->d_nkeys_self, T, m->H, P * batch);
+    gemm<NP, TK_SQUARE>(c, KC_GEMM_ATTN_OUT, m->ao, J, w.self.wo, J, M, D, J, EpiResidual{m->x, D});
+    if (cond0) {
+      norm<NP>(c, m->x, w.ln_cross, BT, D, nullptr, 0, 0, &m->h, nullptr);
+      EpiStoreH16<NP> es;
+      es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, m->h, D, w.wq_cross[0], D, BT, J, D, es);
+      const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
+      const h16_t* kc[2] = {m->kc.p[0] + loff, m->kc.p[NP - 1] + loff};
+      Planes vt;
+      vt.p[0] = m->vtc.p[0] + loff;
+      vt.p[1] = NP == 2 ? m->vtc.p[1] + loff : nullptr;
+      attention<NP>(c, KC_ATTN_CROSS, m->cq, J, kc, J, (size_t)m->S_pad * J, m->S_pad, vt, m->S_pad,
+                    (size_t)J * m->S_pad, m->ao, J, m->d_nkeys_cross, T, m->H, batch, m->cross_ksplit);
+      gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, m->ao, J, w.wo_cross[0], J, BT, D, J, EpiResidual{m->x, D});
+    }
+    norm<NP>(c, m->x, w.ln_mlp, M, D, m->d_film, slots, 2 * l + 1, &m->h, nullptr);
+    EpiGeglu<NP> eg;
+    eg.out[0] = m->g.p[0]; eg.out[1] = m->g.p[NP - 1]; eg.ldc = F;
+    gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, m->h, D, w.mlp.wi, D, M, 2 * F, D, eg);
+    gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, m->g, F, w.mlp.wo, F, M, D, F, EpiResidual{m->x, D});
+  }
+  norm<NP>(c, m->x, m->dec_final_ln, M, D, nullptr, 0, 0, nullptr, m->h32);
+  gemm32(c, KC_FINAL_PROJ, m->h32, D, m->w_spec_out, m->ND, M, m->ND, D, EpiF32Store{m->eps, m->ND});
+}
+
+#endif   // MSD_EXPERIMENTS
 
 // The key split exists to fill the chip when heads x query groups alone cannot (48 blocks at one song); with
 // several songs per handle the (head, query group, song) blocks already cover the CUs, and every split costs a
 // partial round trip + the merge launch: split only as far as ~192 blocks need.
+#if MSD_EXPERIMENTS
+template <int NP>
+void chain_launch(Ctx& c, const MlpChainParams<NP>& cp, int /*layer*/) {
+  msd_model* m = c.m;
+  c.begin(KC_CHAIN_MLP);
+  const bool bn96 = (3 * m->J) % 96 == 0 && (2 * m->J) % 96 == 0;
+  hipError_t e;
+  if (m->chain_mode == 2) e = bn96 ? launch_mlp_chain_ps<NP, 96>(cp, m->cus, c.s) : launch_mlp_chain_ps<NP, 64>(cp, m->cus, c.s);
+  else e = bn96 ? launch_mlp_chain<NP, 96>(cp, m->cus, c.s) : launch_mlp_chain<NP, 64>(cp, m->cus, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(KC_CHAIN_MLP);
+}
+#endif
 
 inline int cross_ksplit_for(const msd_model* m, int batch) {
+  if (m->cross_ksplit_fixed) return m->cross_ksplit;
   const int blocks = m->H * (m->T / 64) * batch;
   int ks = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
   return ks < m->cross_ksplit ? ks : m->cross_ksplit;
 }
 
 template <int NP>
-void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
-  // P passes of `batch` songs: rows [0, BT) are the conditional pass when `cond0`, rows [BT, 2 BT) the unconditional one
+void decoder_layers(Ctx& c, int batch, int P, bool cond0, int row0 = 0) {
   msd_model* m = c.m;
+#if MSD_EXPERIMENTS
+  if (!m->fold_norm) { decoder_layers_unfolded<NP>(c, batch, P, cond0); return; }
+#endif
+  // `row0`: first activation row of this chain (a multiple of T).  The conditional and the
+  // unconditional CFG pass never exchange data inside the decoder (self-attention is per
+  // segment), so enqueue_step can run them as two concurrent chains over disjoint row ranges.
+  auto shift = [&](const Planes& b, size_t elems) {
+    Planes r;
+    r.p[0] = b.p[0] + elems;
+    r.p[1] = b.p[1] ? b.p[1] + elems : nullptr;
+    return r;
+  };
   const int D = m->D, J = m->J, F = m->F, T = m->T;
   const int BT = batch * T, M = P * BT;
   const int slots = 2 * m->Ld, tiles = D / kNarrowTile;
-  const Planes &y = m->y, &qk = m->qk, &vts = m->vt, &ao = m->ao, &gb = m->g;
-  float* const x = m->x;
-  float* const ssq = m->ssq;
-  float* const eps = m->eps;
-  const int* const nkeys_self = m->d_nkeys_self;
+  const Planes y = shift(m->y, (size_t)row0 * D), qk = shift(m->qk, (size_t)row0 * 2 * J);
+  const Planes vts = shift(m->vt, (size_t)row0 * J), ao = shift(m->ao, (size_t)row0 * J);
+  const Planes gb = shift(m->g, (size_t)row0 * F);
+  float* const x = m->x + (size_t)row0 * D;
+  float* const ssq = m->ssq + (size_t)row0 * tiles;
+  float* const eps = m->eps + (size_t)row0 * m->ND;
+  const int* const nkeys_self = m->d_nkeys_self + row0 / T;
   auto rowscale = [&](const float* bias, int stride) {
     RowScale r;
     r.ssq = ssq; r.tiles = tiles; r.inv_d = 1.0f / (float)D; r.bias = bias; r.bias_step_stride = stride;
@@ -949,6 +1208,11 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     eq.rsc = rowscale(m->d_bw_self + (size_t)l * 3 * J, m->Ld * 3 * J);
     return eq;
   };
+#if MSD_EXPERIMENTS
+  const bool chain = m->chain_mlp && NP == 2 && M % 64 == 0 && M < big_m_threshold();
+#else
+  constexpr bool chain = false;
+#endif
   for (int l = 0; l < m->Ld; ++l) {
     const DecLayerW& w = m->dec[l];
     // (i) self-attention block (network.py:174-193).  Layer 0 is fed by the input projection; later layers consume
@@ -957,14 +1221,56 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     // wave of its own): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional pass) .
     // cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
     const bool last_layer = (l + 1 == m->Ld);
-    {
+#if MSD_EXPERIMENTS
+    // Hoisted query projection of the cross-attention (exact algebra, n_cross == 1; docs/history.md): 0 .. +1 % step time
+    const TileShape tq = pick_tile<NP, TK_QKV>(M, 3 * J, 2 * J);
+    const bool hoist = m->hoist_q && cond0 && NP == 2 && row0 == 0 && !chain && tq.bm == 64 && J % tq.bn == 0 && BT % 64 == 0 &&
+                       pick_tile<NP, TK_SQUARE>(M, D, 0).bm == kNarrowTile && pick_tile<NP, TK_SQUARE>(BT, J, 0).bm == kNarrowTile;
+#else
+    constexpr bool hoist = false;
+#endif
+    if (!chain || l == 0) {
       const EpiQKV<NP> eq = qkv_epi(l);
       WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
+#if MSD_EXPERIMENTS
+      // The layer's cached cross-attention K and V^T (14 MB at base, HBM-cold at every step) riding on this launch's
+      // prefetch wave (MSD_PF_KV=1): +2.5 % step time, docs/history.md
+      if (kPfWave && m->prefetch && m->pf_kv && cond0 && NP == 2 && batch == 1 && m->n_cross == 1 && row0 == 0) {
+        const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
+        PrefetchTarget tk, tv;
+        tk.set(m->kc.p[0] + loff, m->kc.p[1] + loff, m->S_pad, J * 2, J * 2);
+        tk.dyn = m->d_nkeys_cross; tk.dyn_mode = 1;
+        tv.set(m->vtc.p[0] + loff, m->vtc.p[1] + loff, J, m->S_pad * 2, m->S_pad * 2);
+        tv.dyn = m->d_nkeys_cross; tv.dyn_mode = 2;
+        if (tv.lpr <= 64) { pf.add(tk); pf.add(tv); }
+      }
+      if (hoist) {
+        if constexpr (NP == 2) {
+          GemmParams p1 = gp<NP>(y, D, w.self.wqkv, D, M, 3 * J, D);
+          p1.pf = pf; if (p1.pf.n > 1) p1.pf.n = 1;
+          p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_QKV + 1u;
+          set_xcd_grid(m, p1, KC_GEMM_QKV, M, 64);
+          GemmParams p2 = gp<NP>(m->yc, D, w.wq_cross[0], D, BT, J, D);
+          p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
+          set_xcd_grid(m, p2, KC_GEMM_CROSS_Q, BT, 64);
+          EpiStoreF32 ef;
+          ef.out = m->qpart; ef.ldc = J;
+          c.begin(KC_GEMM_QKV);
+          const hipError_t e = tq.bn == 96 ? launch_gemm_h16_dual<NP, 64, 96, 3>(p1, eq, p2, ef, c.s)
+                                           : launch_gemm_h16_dual<NP, 64, 64, 3>(p1, eq, p2, ef, c.s);
+          if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+          c.end(KC_GEMM_QKV);
+        }
+      } else
+#endif
       gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
       WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
+#if MSD_EXPERIMENTS
+      if (cond0 && hoist) pf = prefetch_of<NP>(m, w.w2, J, J);
+#endif
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
     }
@@ -976,13 +1282,34 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
+#if MSD_EXPERIMENTS
+    if (hoist) {   // out-projection + second half of the hoisted query projection in one launch
+      if constexpr (NP == 2) {
+        er.g_lo = nullptr; er.g_lo_stride = 0;   // the conditional rows' y = x1 (.) gamma_cross has no reader any more
+        GemmParams p1 = gp<NP>(ao, J, w.self.wo, J, M, D, J);
+        p1.sat = m->d_sat; p1.sat_tag = (unsigned)KC_GEMM_ATTN_OUT + 1u;
+        set_xcd_grid(m, p1, KC_GEMM_ATTN_OUT, M, kNarrowTile);
+        p1.pf = prefetch_of<NP>(m, w.wo_cross[0], D, J);
+        GemmParams p2 = gp<NP>(ao, J, w.w2, J, BT, J, J);
+        p2.sat = m->d_sat; p2.sat_tag = (unsigned)KC_GEMM_CROSS_Q + 1u;
+        set_xcd_grid(m, p2, KC_GEMM_CROSS_Q, BT, kNarrowTile);
+        EpiAddStoreH16<NP> es;
+        es.out[0] = m->cq.p[0]; es.out[1] = m->cq.p[NP - 1]; es.ldc = J;   // stored un-normalised
+        es.addend = m->qpart; es.ld_add = J;
+        c.begin(KC_GEMM_ATTN_OUT);
+        const hipError_t e = launch_gemm_h16_dual<NP, kNarrowTile, kNarrowTile, 4>(p1, er, p2, es, c.s);
+        if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+        c.end(KC_GEMM_ATTN_OUT);
+      }
+    } else
+#endif
     gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
       // projections run before the first output projection rewrites y
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
-      for (int e = 0; e < m->n_cross; ++e) {
+      for (int e = 0; e < m->n_cross && !hoist; ++e) {
         const Planes& cq = e == 0 ? m->cq : m->cq2;
         EpiStoreH16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
@@ -1000,11 +1327,15 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
         // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
         const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
         const int ks = want < cap ? want : cap;
-        const bool warm_mlp_in = e + 1 == m->n_cross;
+        // (round 2's chain, MSD_CHAIN=1, is kept as it was measured: without this touch)
+        bool warm_mlp_in = e + 1 == m->n_cross && !chain;
+#if MSD_EXPERIMENTS
+        if (e + 1 == m->n_cross && chain && m->chain_mode == 2) warm_mlp_in = true;
+#endif
         const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
-                      batch, ks, region, &pf);
+                      batch, ks, region, &pf, -1, hoist ? ssq : nullptr);
       }
       // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
       // other; the last one also writes the folded-norm inputs of the MLP block
@@ -1026,10 +1357,41 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     eo.g_lo = eo.g_hi = last ? m->dec_final_ln : g_tab(2 * (l + 1));  // decoder_norm has no FiLM
     eo.g_lo_stride = eo.g_hi_stride = last ? 0 : slots * D;
     eo.split_row = 0;
+#if MSD_EXPERIMENTS
+    if (m->hoist_q && cond0 && !last && row0 == 0) {   // x (.) gamma_cross of the NEXT layer, conditional rows
+      eo.y2[0] = m->yc.p[0]; eo.y2[1] = m->yc.p[NP - 1]; eo.g2 = m->dec[l + 1].ln_cross; eo.y2_rows = BT;
+    }
+    if constexpr (NP == 2) {
+      if (chain) {   // MLP-in -> MLP-out -> QKV of layer l+1: one XCD-resident launch (tools/ubench/exp/chain.h)
+        MlpChainParams<NP> cp;
+        cp.g_in = gp<NP>(y, D, w.mlp.wi, D, M, 2 * F, D);     cp.e_in = eg;
+        cp.g_out = gp<NP>(gb, F, w.mlp.wo, F, M, D, F);       cp.e_out = eo;
+        cp.has_qkv = last ? 0 : 1;
+        cp.g_qkv = gp<NP>(y, D, m->dec[last ? l : l + 1].self.wqkv, D, M, 3 * J, D);
+        cp.e_qkv = qkv_epi(last ? l : l + 1);
+        cp.bar = m->d_bar; cp.err = m->d_chain_err;
+        if (m->chain_mode == 2) {   // phases 1 / 2 weights -> memory-side cache, from the launch's prefetch wave
+          cp.pf.add(weights_target<NP>(m, w.mlp.wo, D, F));
+          if (!last) cp.pf.add(weights_target<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D));
+        }
+        chain_launch<NP>(c, cp, l);
+        continue;
+      }
+    }
+#endif
     {
       const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
       WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+#if MSD_EXPERIMENTS
+      if (hoist && !last_layer) pf_qkv.add(weights_target<NP>(m, m->dec[l + 1].wq_cross[0], J, D));   // first half of its hoisted q
+      if constexpr (NP == 2) {
+        if (splitk_fits(m, NP, M, D, F)) {
+          gemm_splitk<NP>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, &pf_qkv);
+          continue;
+        }
+      }
+#endif
       gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
     }
   }
@@ -1056,17 +1418,31 @@ template <int NP>
 void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
   msd_model* m = c.m;
   const int BT = batch * m->T;
+#if MSD_EXPERIMENTS
+  if (!m->fold_norm) {
+    gemm32(c, KC_IN_PROJ, m->z, m->ND, m->w_in_proj, m->D, BT, m->D, m->ND,
+           EpiF32InProj{m->x, m->dec_pos, m->D, m->T, BT, P});
+    return;
+  }
+#endif
   EpiInProj<NP> ei;
   ei.x = m->x; ei.ldx = m->D; ei.pos = m->dec_pos; ei.T = m->T; ei.pass_rows = BT; ei.passes = P;
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
   WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
+#if MSD_EXPERIMENTS
+  if (m->hoist_q) {
+    ei.y2[0] = m->yc.p[0]; ei.y2[1] = m->yc.p[NP - 1]; ei.g2 = m->dec[0].ln_cross;
+    pf.add(weights_target<NP>(m, m->dec[0].wq_cross[0], m->J, m->D));
+  }
+#endif
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 
 // z (fp32) -> bf16 planes, after z was written from outside the sampler kernel
 void split_z(msd_model* m, int64_t n, hipStream_t s) {
+  if (!m->fold_norm) return;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, m->zp.p[0],
                      m->NP == 2 ? m->zp.p[1] : (h16_t*)nullptr, n, m->d_sat, (unsigned)KC_SAMPLER + 1u);
 }
@@ -1075,7 +1451,22 @@ template <int NP>
 void enqueue_step(Ctx& c, int batch) {
   msd_model* m = c.m;
   const int P = m->passes;
-  in_proj<NP>(c, batch, P, /*publish_step=*/true);
+  in_proj<NP>(c, batch, P, /*publish_step=*/m->fold_norm);
+#if MSD_EXPERIMENTS
+  if (m->dual_chain && P == 2 && m->fold_norm && !m->prof.on) {
+    // two concurrent chains (graph branches): conditional rows [0, BT) with cross-attention on
+    // the caller's stream, unconditional rows [BT, 2BT) on the side stream; joined for the sampler
+    const int BT = batch * m->T;
+    hipError_t e = hipEventRecord(m->ev_fork, c.s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(m->side_stream, m->ev_fork, 0);
+    Ctx c2{m, m->side_stream};
+    decoder_layers<NP>(c2, batch, 1, false, BT);
+    if (e == hipSuccess) e = hipEventRecord(m->ev_join, m->side_stream);
+    decoder_layers<NP>(c, batch, 1, true, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c.s, m->ev_join, 0);
+    if (c.err == hipSuccess) c.err = c2.err != hipSuccess ? c2.err : e;
+  } else
+#endif
   decoder_layers<NP>(c, batch, P, true);
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
@@ -1083,12 +1474,15 @@ void enqueue_step(Ctx& c, int batch) {
   sp.cond_wt = m->cfg.cfg_weight; sp.clip_x0 = m->cfg.clip_x0;
   sp.ddim = m->cfg.sampler == MSD_SAMPLER_DDIM;
   sp.model_output = m->cfg.model_output;
-  sp.z_hi = m->zp.p[0];
-  sp.z_lo = m->NP == 2 ? m->zp.p[1] : nullptr;
+  sp.z_hi = m->fold_norm ? m->zp.p[0] : nullptr;
+  sp.z_lo = (m->fold_norm && m->NP == 2) ? m->zp.p[1] : nullptr;
   sp.sat = m->d_sat; sp.sat_tag = (unsigned)KC_SAMPLER + 1u;
   c.begin(KC_SAMPLER);
-  sp.step_from_slot1 = 1;
+  sp.step_from_slot1 = m->fold_norm ? 1 : 0;
   launch_sampler_step(sp, c.s);
+#if MSD_EXPERIMENTS
+  if (!m->fold_norm) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, c.s, m->d_step);
+#endif
   c.end(KC_SAMPLER);
 }
 
@@ -1098,8 +1492,57 @@ void set_func_attrs() {
   (void)attention_prepare<2, 2>();
   (void)prepare_gemms<1>();
   (void)prepare_gemms<2>();
+#if MSD_EXPERIMENTS
+  (void)mlp_chain_prepare<2, 96>();
+  (void)mlp_chain_prepare<2, 64>();
+  (void)mlp_chain_ps_prepare<2, 96>();
+  (void)mlp_chain_ps_prepare<2, 64>();
+  (void)gemm_h16_splitk_prepare<2, kSkBM, kSkBN, kSkNS, kSkSplit, EpiResidualNorm<2>>();
+  (void)gemm_h16_wide_prepare<2, 128, EpiGeglu<2>>();
+  (void)gemm_h16_ls_prepare<2, 128, EpiGeglu<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiQKV<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 128, EpiGeglu<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiResidual>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiResidualNorm<2>>();
+  (void)gemm_h16_pair_prepare<2, 128, 96, EpiStoreH16<2>>();
+  (void)gemm_h16_dual_prepare<2, kNarrowTile, kNarrowTile, 4, EpiResidualNorm<2>, EpiAddStoreH16<2>>();
+  (void)gemm_h16_dual_prepare<2, 64, 96, 3, EpiQKV<2>, EpiStoreF32>();
+  (void)gemm_h16_dual_prepare<2, 64, 64, 3, EpiQKV<2>, EpiStoreF32>();
+#endif
 }
 
+#if MSD_EXPERIMENTS
+// The A/B switches of the experiments build (tools/ubench/exp/README.md lists them with what each measured).
+void exp_read_launch_env(msd_model* m) {   // switches that only matter while a step is being captured / launched
+  if (const char* v = getenv("MSD_XCD_ROWS")) m->xcd_rows = atoi(v) > 0 ? atoi(v) : 2;
+  if (const char* v = getenv("MSD_XCD_WALK_N")) m->xcd_walk_n = atoi(v);
+}
+void exp_read_env(msd_model* m) {
+  const msd_config* cfg = &m->cfg;
+  if (const char* v = getenv("MSD_FOLD_NORM")) m->fold_norm = atoi(v) != 0;
+  if (const char* v = getenv("MSD_DUAL_CHAIN")) m->dual_chain = atoi(v) != 0;
+  if (const char* v = getenv("MSD_GRAPH_STEPS")) m->graph_steps = atoi(v) > 0 ? atoi(v) : 1;
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;
+  if (const char* v = getenv("MSD_HOIST_Q")) m->hoist_q = atoi(v) != 0;
+  if (const char* v = getenv("MSD_PF_KV")) m->pf_kv = atoi(v) != 0;
+  if (const char* v = getenv("MSD_SPLITK")) m->splitk = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_PAIR")) m->big_pair = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_WIDE")) m->big_wide = atoi(v) != 0;
+  if (const char* v = getenv("MSD_BIG_LS")) m->big_ls = atoi(v) != 0;
+  if (const char* v = getenv("MSD_TILE48")) m->tile48 = atoi(v) != 0;
+  if (const char* v = getenv("MSD_ATT_QP_SELF")) m->att_qp_self = atoi(v) & 3;
+  if (const char* v = getenv("MSD_ATT_QP_CROSS")) m->att_qp_cross = atoi(v) & 3;
+  if (const char* v = getenv("MSD_SPLITK_MINK")) m->splitk_min_k = atoi(v);
+  exp_read_launch_env(m);
+  // chain.h: needs the block -> XCD round robin over 8 XCDs with equal CU counts, the folded norms, two planes and
+  // tile-aligned widths (64 x 128 gated tiles, 64 x 32 output tiles, 64 x 96 or 64 x 64 QKV tiles)
+  const char* v = getenv("MSD_CHAIN");
+  m->chain_mlp = (v && atoi(v) != 0) && m->fold_norm && m->NP == 2 && m->cus >= 8 &&
+                 m->cus % 8 == 0 && (2 * cfg->mlp_dim) % 128 == 0 && cfg->emb_dim % 32 == 0 &&
+                 (3 * cfg->num_heads * kHeadDim) % 64 == 0;
+  m->chain_mode = v ? atoi(v) : 0;
+}
+#endif
 
 }  // namespace
 
@@ -1183,12 +1626,19 @@ int msd_create(const msd_config* cfg, msd_model** out) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       m->cus = cus;
   }
+#if MSD_EXPERIMENTS
+  exp_read_env(m);
+#endif
   // encode_impl writes round_up(Lv, 64) token rows and then round_up(Cv, 64) context rows from row Lv
   m->S_pad = round_up(m->L, 64) + round_up(m->C, 64);
   // decoder_cross_attend_style (network.py:199-235): with one encoding both styles are the same module
   m->n_cross = (cfg->cross_attend_sum && cfg->has_context) ? 2 : 1;
   m->key_off[0] = 0; m->key_off[1] = round_up(m->L, 64);
   m->Lenc_pad = round_up(m->L > m->C ? m->L : m->C, 64);
+#if MSD_EXPERIMENTS
+  if (m->n_cross == 2 && !m->fold_norm) return bad("sum_cross_attends needs the folded-norm path (MSD_FOLD_NORM=1)");
+  m->hoist_q = m->hoist_q && m->fold_norm && m->NP == 2 && m->n_cross == 1 && m->D % 128 == 0 && !m->dual_chain && !m->chain_mlp;
+#endif
   declare_weights(m);
   *out = m;
   set_func_attrs();
@@ -1206,9 +1656,18 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->x, Mmax * D));
   TRY(palloc(m, &m->y, Mmax * D));
   TRY(palloc(m, &m->zp, (size_t)m->Bmax * T * m->ND));
+#if MSD_EXPERIMENTS
+  if (m->hoist_q) {
+    TRY(palloc(m, &m->yc, (size_t)m->Bmax * T * D));
+    TRY(dalloc(m, &m->qpart, (size_t)m->Bmax * T * J));
+  }
+#endif
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
   m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
+#if MSD_EXPERIMENTS
+  if (const char* v = getenv("MSD_CROSS_KSPLIT")) { m->cross_ksplit = atoi(v) > 0 ? atoi(v) : 1; m->cross_ksplit_fixed = true; }
+#endif
   TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
   TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
   TRY(palloc(m, &m->h, Mmax * D));
@@ -1228,6 +1687,19 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->d_step, 2));
   TRY(dalloc(m, &m->d_absmax, 1));
   TRY(dalloc(m, &m->d_sat, 1));
+#if MSD_EXPERIMENTS
+  TRY(dalloc(m, &m->d_bar, 8 * kBarStride));
+  TRY(dalloc(m, &m->d_chain_err, 1));
+  TRY(dalloc(m, &m->d_sk_err, 1));
+  if (D % kSkBN == 0 && Mmax % kSkBM == 0) {
+    m->sk_tiles = (Mmax / kSkBM) * (size_t)(D / kSkBN);
+    if (m->sk_tiles * kSkSplit <= (size_t)(m->cus > 0 ? m->cus : 0)) {
+      TRY(dalloc(m, &m->sk_part, m->sk_tiles * kSkSplit * kSkBM * kSkBN));
+      TRY(dalloc(m, &m->sk_cnt, m->sk_tiles));
+      TRY(dalloc(m, &m->sk_xcc, m->sk_tiles * kSkSplit));
+    }
+  }
+#endif
   HIP_TRY(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_sat), sizeof(unsigned), hipHostMallocDefault));
   *m->h_sat = 0;
   TRY(dalloc(m, &m->d_nkeys_self, (size_t)m->passes * m->Bmax));
@@ -1258,6 +1730,11 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   HIP_TRY(m, hipEventCreate(&m->prof.e0));
   HIP_TRY(m, hipEventCreate(&m->prof.e1));
   HIP_TRY(m, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+#if MSD_EXPERIMENTS
+  HIP_TRY(m, hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+  HIP_TRY(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  HIP_TRY(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+#endif
   return MSD_OK;
 }
 
@@ -1268,6 +1745,11 @@ void msd_destroy(msd_model* m) {
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+#if MSD_EXPERIMENTS
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+#endif
   if (m->noise_own) (void)hipFree(m->noise_own);
   if (m->h_sat) (void)hipHostFree(m->h_sat);
   for (void* p : m->allocs) (void)hipFree(p);
@@ -1336,6 +1818,29 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross[e], 0, 0))) return rc;
     }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
+#if MSD_EXPERIMENTS
+    if (m->hoist_q) {
+      // q' = (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  (x0 (.) gamma) . Wq + ao . (Wo . diag(gamma) . Wq):
+      // the second matrix in float32 on the exact-fp32 MFMA, then packed like any other weight
+      const std::string cp = lp + "/MultiHeadDotProductAttention_0";
+      float *gwq = nullptr, *w2 = nullptr;
+      HIP_TRY(m, hipMalloc(&gwq, (size_t)D * J * sizeof(float)));
+      HIP_TRY(m, hipMalloc(&w2, (size_t)J * J * sizeof(float)));
+      hipLaunchKernelGGL(scale_rows_kernel, dim3((D * J + 255) / 256), dim3(256), 0, s, W(m, cp + "/query/kernel"),
+                         w.ln_cross, gwq, D, J);
+      GemmF32Params gp2;
+      gp2.A = W(m, lp + "/self_attention/out/kernel"); gp2.B = gwq; gp2.lda = D; gp2.ldb = J; gp2.M = J; gp2.N = J; gp2.K = D;
+      hipError_t e = launch_gemm_f32(gp2, EpiF32Store{w2, J}, s);
+      if (e == hipSuccess) {
+        if ((rc = palloc(m, &w.w2, (size_t)J * J)) == MSD_OK) rc = pack(m, s, w2, J, J, w.w2, 0, 0);
+      }
+      const hipError_t es = hipStreamSynchronize(s);
+      (void)hipFree(gwq); (void)hipFree(w2);
+      if (rc) return rc;
+      HIP_TRY(m, e);
+      HIP_TRY(m, es);
+    }
+#endif
   }
   m->dec_final_ln = W(m, "decoder/decoder_norm/scale");
   m->w_spec_out = W(m, "decoder/spec_out_dense/kernel");
@@ -1361,6 +1866,9 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     const size_t kv = (size_t)m->Ld * m->Bmax * m->S_pad * J * 2 * planes;
     const size_t per_step = per_layer * m->Ld + kv;
     bool decided = m->cfg.weight_prefetch != 0;
+#if MSD_EXPERIMENTS
+    if (getenv("MSD_PREFETCH")) decided = true;
+#endif
     if (!decided) m->prefetch = per_step > ((size_t)256 << 20);
   }
   HIP_TRY(m, hipStreamSynchronize(s));
@@ -1456,6 +1964,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
+  if (int rc = reset_sync_words(m, s)) return rc;
   HIP_TRY(m, hipStreamSynchronize(s));  // host temporaries above are on the stack
 
   // One graph = `graph_steps` consecutive DDPM steps (the scan index lives in device memory, so
@@ -1496,7 +2005,9 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   HIP_TRY(m, hipGetLastError());
   // The call ends with ONE stream synchronisation (tens of microseconds against a ~1 s segment): behind it the
   // half-plane range flag and the chain kernels' barrier flag are read, so that a bad run fails THIS call.
-  return check_range(m, s, "msd_sample");
+  const int rc = check_range(m, s, "msd_sample");
+  if (rc) return rc;
+  return check_sync_words(m, "msd_sample");
 }
 
 int msd_reset_graph(msd_model* m) {
@@ -1504,6 +2015,10 @@ int msd_reset_graph(msd_model* m) {
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
   m->graph_batch = 0;
+#if MSD_EXPERIMENTS
+  if (const char* v = getenv("MSD_PREFETCH")) m->prefetch = atoi(v) != 0;   // launch-time switch: re-read for A/B sweeps
+  exp_read_launch_env(m);
+#endif
   return MSD_OK;
 }
 
@@ -1520,6 +2035,7 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   if (int rc0 = arm_range(m, s)) return rc0;
   HIP_TRY(m, hipMemcpyAsync(m->d_step, st, sizeof(st), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipMemcpyAsync(m->z, z_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (int rc = reset_sync_words(m, s)) return rc;
   HIP_TRY(m, hipStreamSynchronize(s));
   split_z(m, n, s);
   Ctx c{m, s};
@@ -1527,7 +2043,8 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   else { in_proj<1>(c, batch, 1); decoder_layers<1>(c, batch, 1, include_conditioning != 0); }
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "decoder pass failed: %s", hipGetErrorString(c.err));
   HIP_TRY(m, hipMemcpyAsync(eps_out_dev, m->eps, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return check_range(m, s, "msd_decoder_pass");   // synchronises
+  if (int rc = check_range(m, s, "msd_decoder_pass")) return rc;   // synchronises
+  return check_sync_words(m, "msd_decoder_pass");
 }
 
 int msd_get_schedule(const msd_model* m, float* host_out) {
@@ -1603,6 +2120,7 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
+  if (int rc2 = reset_sync_words(m, s)) return rc2;
   HIP_TRY(m, hipStreamSynchronize(s));
   for (int k = 0; k < KC_COUNT; ++k) { m->prof.ms[k] = 0; m->prof.launches[k] = 0; }
   m->prof.on = true;
@@ -1613,6 +2131,7 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   m->prof.on = false;
   if (c.err != hipSuccess) { (void)hipStreamSynchronize(s); return fail(m, MSD_ERR_HIP, "profile run failed: %s", hipGetErrorString(c.err)); }
   if (int rc2 = check_range(m, s, "msd_profile_steps")) return rc2;   // synchronises; the timed steps ran with the flag armed
+  if (int rc2 = check_sync_words(m, "msd_profile_steps")) return rc2;
   for (int k = 0; k < MSD_MAX_KERNEL_CLASSES; ++k) {
     ms_out[k] = k < KC_COUNT ? m->prof.ms[k] : 0.0;
     launches_out[k] = k < KC_COUNT ? m->prof.launches[k] : 0;
@@ -1896,7 +2415,26 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     p1.xcd_rows = 2; p1.xcd_walk_n = 1;
     fl.arm(p1);
     if (folded == 2) {   // the producer as the 4-way split-K launch of the experiments build (gemm_h16_splitk_kernel)
+#if !MSD_EXPERIMENTS
       return MSD_ERR_UNSUPPORTED;
+#else
+      int cus = 0, dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const int tiles = (M / kSkBM) * (D / kSkBN);
+      p1.xcd_rows = (M % kSkBM || D % kSkBN) ? 0 : splitk_xcd_rows(M / kSkBM, D / kSkBN);
+      if (p1.xcd_rows == 0 || K % (kSkSplit * kGemmBK) || tiles * kSkSplit > cus) return MSD_ERR_INVALID_ARGUMENT;
+      p1.sk_part = sc.get<float>((size_t)tiles * kSkSplit * kSkBM * kSkBN);
+      p1.sk_cnt = sc.get<unsigned>(tiles);
+      p1.sk_xcc = sc.get<unsigned>((size_t)tiles * kSkSplit);
+      sk_err = sc.get<int>(1);
+      p1.sk_err = sk_err;
+      if (!p1.sk_part || !p1.sk_cnt || !p1.sk_xcc || !sk_err) return MSD_ERR_HIP;
+      for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {   // three launches over the same (monotonic) arrival counters
+        if (rep) (void)hipMemcpyAsync(x_out_dev, x_in_dev, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s);
+        e = launch_gemm_h16_splitk<2, kSkBM, kSkBN, kSkNS, kSkSplit>(p1, er, s);
+      }
+#endif
     } else if (folded == 3) {   // the producer on 32 x 48 tiles (one partial sum per row and tile + zeroed spare slots)
       if (D % kWide48 || M % 32) return MSD_ERR_INVALID_ARGUMENT;
       if (e == hipSuccess) e = launch_gemm_h16_dma<2, 32, kWide48, 4>(p1, er, s);

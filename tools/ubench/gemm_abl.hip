@@ -2,7 +2,7 @@
 //   0 full | 1 no MFMA | 2 no LDS fragment reads | 3 no DMA inside the loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
+#include "exp/src_r04/gemm_h16.h"   // round-4 sources: the ablation switches live there, not in the product
 using namespace msd;
 template <int NP, int BM, int BN, int NS>
 double run(int M, int N, int K, int iters) {

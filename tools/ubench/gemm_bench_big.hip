@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
+#include "exp/src_r04/gemm_h16.h"   // round-4 sources: the ablation switches live there, not in the product
 using namespace msd;
 
 template <int NP, int BM, int BN, int NS>

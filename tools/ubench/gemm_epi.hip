@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_epi_0 gemm_epi.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
+#include "exp/src_r04/gemm_h16.h"   // round-4 sources: the ablation switches live there, not in the product
 using namespace msd;
 
 template <class T> T* dmalloc(size_t n, int fill = 0) { T* p; (void)hipMalloc(&p, n * sizeof(T)); (void)hipMemset(p, fill, n * sizeof(T)); return p; }

@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_ksweep_0 gemm_ksweep.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../music-spectrogram-diffusion_amd/csrc/gemm_h16.h"
+#include "exp/src_r04/gemm_h16.h"   // round-4 sources: the ablation switches live there, not in the product
 using namespace msd;
 
 template <int NP, int BM, int BN, int NS>

@@ -5,7 +5,7 @@
 // WITHOUT its reduction, by running the product kernel on (M, s * N, K / s): same block count, same
 // per-block ingest, same output bytes per block as the split would have -- an upper bound on the gain,
 // to be compared with the <= 1-2 us a same-XCD reduction hand-off costs (tools/ubench/xcd_sync.hip).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I music-spectrogram-diffusion_amd/csrc -o tools/ubench/gemm_splitk_0 tools/ubench/gemm_splitk.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/ubench/exp/src_r04 -o tools/ubench/gemm_splitk_0 tools/ubench/gemm_splitk.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
