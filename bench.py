@@ -23,6 +23,11 @@ N > 1: one process per GPU.  --mode (sharding.py):
   masked     one song of N*K segments, chunk heads run context-masked (no message, not parity-exact at
              the N-1 cuts: the reference's own i == 0 / always_mask_context behaviour there)
 value = frames of all ranks / max-over-ranks time; per-GPU work is K segments in every mode ("weak").
+The plain N > 1 line (default --mode replicas) also carries a `handoff` leg: BASELINE config 4's partitioning -- the
+10-minute workload, 118 segments, as a wavefront of ceil(118 / N) songs x N segments with the device-to-device context
+hand-off (per-rank segments capped by --handoff-max-segments) -- timed after the replicas region, with each rank's
+idle fraction; a hang anywhere on that message path (first contact with RCCL point-to-point) ends the leg after
+--handoff-timeout seconds and the line is printed with an `error` field instead of never.
 
 The JSON line also carries
   roofline      dominant kernel class: algorithmic FLOP per launch / mean launch
@@ -352,9 +357,87 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return {'ok': bool(flag.item() == 1.0), 'message_bytes': int(np.prod(shape)) * 4, 'hops': world - 1,
             'us_per_hop': round(float(tt.item()) / rounds / max(world - 1, 1) * 1e6, 1),
-            'note': 'header-checked message of sharding.chained_predict, batch_isend_irecv of the device tensor (RCCL p2p); one message per chunk boundary in --mode chained'}
+            'note': 'header-checked message of sharding.chained_predict: isend / recv of the device tensor (RCCL point-to-point, one communicator per peer pair); one message per chunk boundary in --mode chained'}
   except Exception as e:  # never let the probe take the benchmark down
     return {'ok': False, 'error': repr(e)[:200]}
+
+
+class Watchdog:
+  """Bounded wait around a region that may hang in a communication call (first contact with RCCL point-to-point on a
+  node nobody has run on).  A hung NCCL / HIP wait cannot be interrupted from Python, so when the time is up the
+  timer thread runs `on_timeout` (rank 0: print the benchmark line it already has, with an error field) and ends the
+  PROCESS with os._exit -- every rank arms its own, so the launcher sees all ranks leave."""
+
+  def __init__(self, seconds, on_timeout):
+    import threading
+    self.t = threading.Timer(seconds, self._fire)
+    self.t.daemon = True
+    self.on_timeout = on_timeout
+    self.seconds = seconds
+
+  def _fire(self):
+    try:
+      self.on_timeout(self.seconds)
+    finally:
+      sys.stdout.flush()
+      os._exit(0)
+
+  def __enter__(self):
+    self.t.start()
+    return self
+
+  def __exit__(self, *exc):
+    self.t.cancel()
+    return False
+
+
+def handoff_leg(args, model, spec, dist, rank, world, song_tokens, ctx_shape):
+  """BASELINE config 4 as a leg of the plain N > 1 line: the 10-minute workload (--handoff-segments, 118) as a
+  wavefront of K = ceil(118 / N) songs x N segments (beam/evaluation.py:191-223 per song: segment k+1 conditions on
+  segment k's prediction, which arrives from rank k as one device-to-device message); K is capped so that a rank
+  runs at most --handoff-max-segments segments.  Returns the record on every rank (rank 0 prints it)."""
+  import torch
+  from msd_amd import sharding
+  k_songs = min(-(-args.handoff_segments // world), args.handoff_max_segments)
+  songs = [[t[:1] for t in song_tokens(100 + j, world)] for j in range(k_songs)]
+  busy = [0.0]
+
+  def timed_predict_sequence(*a, **kw):
+    _sync(model.device)
+    t0 = time.perf_counter()
+    out = model.predict_sequence(*a, **kw)
+    _sync(model.device)
+    busy[0] += time.perf_counter() - t0
+    return out
+
+  _sync(model.device)
+  dist.barrier()
+  _sync(model.device)
+  t0 = time.perf_counter()
+  outs = sharding.chained_wavefront(timed_predict_sequence, songs, ctx_shape, rank, world,
+                                    comm_device=model.device, seed=100, return_torch=True)   # (song j: noise seed 100 + j)
+  _sync(model.device)
+  mine = time.perf_counter() - t0
+  dist.barrier()
+  _sync(model.device)
+  elapsed = time.perf_counter() - t0
+  finite = all(bool(torch.isfinite(torch.as_tensor(o)).all()) for o in outs)
+  rows = [None] * world
+  dist.all_gather_object(rows, {'rank': rank, 'seconds': round(mine, 4), 'busy_seconds': round(busy[0], 4),
+                                'idle_fraction': round(1.0 - busy[0] / max(elapsed, 1e-9), 4), 'finite': finite})
+  tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+  dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+  elapsed = float(tmax.item())
+  t_frames = spec.task_feature_lengths['targets']
+  frames = k_songs * world * t_frames
+  return {'mode': 'wavefront', 'songs': k_songs, 'segments_per_song': world, 'segments': k_songs * world,
+          'value': round(frames / elapsed, 3), 'unit': 'mel-frames/sec', 'xRTF': round(frames * 320 / 16000.0 / elapsed, 4),
+          'seconds': round(elapsed, 4), 'ideal_efficiency': round(k_songs / (k_songs + world - 1.0), 4),
+          'per_rank': rows, 'ok': all(r['finite'] for r in rows),
+          'data': args.data,
+          'note': 'BASELINE config 4: %d-segment workload as %d songs x %d segments, rank r runs segment r of every song; '
+                  'context hand-off per segment boundary (sharding.chained_wavefront); bit-identical to the sequential songs'
+                  % (args.handoff_segments, k_songs, world)}
 
 
 def model_kwargs(args):
@@ -391,6 +474,12 @@ def main():
                   help='extra leg: this many songs per GPU in one handle (0/1 = skip); N=1 runs only')
   ap.add_argument('--small-segments', type=int, default=12,
                   help="extra leg: BASELINE config 2, the `small` no-context model over this many segments (0 = skip); N=1 runs only")
+  ap.add_argument('--handoff-segments', type=int, default=118,
+                  help='N > 1, --mode replicas: size of the extra `handoff` leg (BASELINE config 4: 10 min of MIDI = 118 segments); 0 = skip')
+  ap.add_argument('--handoff-max-segments', type=int, default=16,
+                  help='cap on the segments one rank runs in the `handoff` leg (its wall time is about this many + N - 1 segments)')
+  ap.add_argument('--handoff-timeout', type=float, default=240.0,
+                  help='seconds after which a hanging hand-off probe / leg is abandoned (the line then carries an error field)')
   ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                   help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the product); 'gloo' is for the CPU test of the launcher")
   ap.add_argument('--model-factory', default='msd_amd:InferenceModel',
@@ -418,10 +507,12 @@ def main():
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=max(60.0, 2 * args.handoff_timeout))   # (a stuck collective aborts instead of hanging for 10 min)
     if on_gpu:
-      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank), timeout=pg_timeout)
     else:
-      dist.init_process_group('gloo', rank=rank, world_size=world)
+      dist.init_process_group('gloo', rank=rank, world_size=world, timeout=pg_timeout)
 
   ranks_seen = None
   if dist is not None:
@@ -508,7 +599,13 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-  handoff = handoff_check(dist, rank, world, model.device, (1, c_len, 128)) if (dist is not None and c_len) else None
+  # the precision each rank ENDED in: range_fallback (on by default) switches a model to bfloat16 planes with a warning
+  # when an activation leaves the half range -- the line must not credit f16x3 with a figure measured in bf16x3
+  precision_ran = getattr(model, 'precision', args.precision)
+  precisions_seen = None
+  if dist is not None:
+    precisions_seen = [None] * world
+    dist.all_gather_object(precisions_seen, precision_ran)
 
   result = None
   if rank == 0:
@@ -598,18 +695,19 @@ def main():
                                   'segment-sequential with context hand-off' if c_len is not None
                                   else 'independent segments (no context), one after the other',
                                   args.steps, t_frames),
-                   'precision': args.precision, 'parallelism': par, 'mode': mode,
+                   'precision': precision_ran, 'precision_requested': args.precision, 'parallelism': par, 'mode': mode,
                    'attention_query_planes': args.attn_planes or 'library default: hi + lo for Q and for the softmax weights'},
         'roofline': roofline,
     }
     if mode == 'replicas':
       result['encode_ms_per_segment'] = round(enc_s / args.steps * 1e3, 3)
       result['sample_ms_per_segment'] = round(smp_s / args.steps * 1e3, 3)
-    if handoff is not None:
-      result['handoff_check'] = handoff
     if ranks_seen is not None:
       result['ranks_seen'] = ranks_seen               # one entry per rank: device / uuid / pid as that rank saw them
       result['per_rank_seconds'] = per_rank_seconds   # each rank's own timed region; `value` uses the maximum
+      result['per_rank_precision'] = precisions_seen  # what each rank's model ended in (range_fallback may switch planes)
+      for r_, p_ in zip(result['ranks_seen'], precisions_seen):
+        r_['precision'] = p_
     if world == 1 and args.batched_songs > 1 and nb == 1:
       result['batched'] = batched_leg(spec, args)
     if world == 1 and args.small_segments > 0 and nb == 1 and args.preset != 'small':
@@ -620,9 +718,34 @@ def main():
         batch['encoder_continuous_inputs'] = np.zeros((1, c_len, 128), np.float32)
         batch['encoder_continuous_mask'] = np.ones((1, c_len), np.int32)
       result['cpu_baseline'] = cpu_baseline(spec, model.params, batch, args.cpu_sample_steps)
+  if dist is not None and c_len:
+    # ---- the message path (probe + BASELINE config 4 leg), AFTER the headline figures are safe: first contact with
+    # RCCL point-to-point on this node may hang; the watchdog then prints the line as it stands with an error field
+    printed = []
+
+    def bail(seconds):
+      if rank == 0 and not printed:
+        result.setdefault('handoff_check', {'ok': False})
+        result['handoff'] = {'ok': False, 'error': 'the hand-off probe / leg did not finish within %.0f s (--handoff-timeout): '
+                                                   'abandoned, replicas figures above are unaffected' % seconds}
+        print(json.dumps(result))
+        printed.append(1)
+
+    with Watchdog(args.handoff_timeout, bail):
+      handoff = handoff_check(dist, rank, world, model.device, (1, c_len, 128))
+      if rank == 0:
+        result['handoff_check'] = handoff
+      if mode == 'replicas' and args.handoff_segments > 0 and nb == 1:
+        try:
+          leg = handoff_leg(args, model, spec, dist, rank, world, song_tokens, ctx_shape)
+        except Exception as e:   # a HandoffError or a transport error on one rank: report, do not lose the line
+          leg = {'ok': False, 'error': repr(e)[:300]}
+        if rank == 0:
+          result['handoff'] = leg
   if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+    with Watchdog(60.0, lambda s_: print(json.dumps(result)) if rank == 0 else None):
+      dist.barrier()
+      dist.destroy_process_group()
   if rank == 0:
     print(json.dumps(result))
 

@@ -27,7 +27,7 @@ LIBS = {'f16': (LIB, []), 'bf16': (os.path.join(CSRC, 'libmsd_amd_bf16.so'), ['-
 EXP_SRC = os.path.join(EXP, 'src_r04')   # round 4's sources with the experiments still inside
 EXP_LIBS = {'exp': (LIB_EXP, ['-DMSD_EXPERIMENTS=1'])}
 SOURCES = ['msd_api.hip']
-HEADERS = ['common.h', 'gemm_h16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
+HEADERS = ['common.h', 'phase_stamps.h', 'gemm_h16.h', 'gemm_f32.h', 'attention.h', 'elementwise.h',
            os.path.join('..', '..', 'include', 'msd_amd.h')]
 EXP_HEADERS = ['chain.h', 'gemm_h16_exp.h', 'gemm_splitk_exchange.inc', 'gemm_h16_pair.h', 'gemm_h16_wide.h', 'gemm_h16_ls.h']
 

@@ -123,6 +123,9 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
     import warnings
     warnings.warn('MSD_AMD_LIB=%s does not export %s: those entry points are unbound' % (LIB_PATH, missing), RuntimeWarning)
   if override:
+    if 'msd_version' not in present:   # (the warning above is no help for the one symbol this check needs)
+      raise NativeLibraryError('MSD_AMD_LIB=%s does not export msd_version: cannot verify its ABI (this package binds ABI %d)'
+                               % (LIB_PATH, ABI_VERSION))
     lib.msd_version.restype = ctypes.c_char_p
     ver = lib.msd_version() or b''
     if ('abi %d' % ABI_VERSION).encode() not in ver:

@@ -51,9 +51,10 @@ def _on_device(comm_device) -> bool:
 # float32 [HEADER + C*n]: {magic, song, source rank, payload elements} followed by the previous prediction.  The header
 # makes the ORDER of the messages part of the protocol instead of an assumption: the NCCL / RCCL backend ignores
 # `tag`, so "song j's message is the j-th one from rank r-1" used to rest on FIFO delivery per peer (VERDICT r03 weak
-# #11).  The integers are < 2^24 and therefore exact in float32; the payload is untouched (bit-identical songs).
+# #11).  Every header integer -- the magic included -- is < 2^24 and therefore exact in float32; the payload is
+# untouched (bit-identical songs).
 HEADER = 4
-MAGIC = 20250926.0
+MAGIC = float(0x4D5344)   # "MSD" = 5 067 588 < 2^24
 
 
 class HandoffError(RuntimeError):
@@ -70,9 +71,12 @@ def pack_handoff(payload, song: int, src_rank: int):
 
 def unpack_handoff(msg, song: int, src_rank: int, context_shape):
   """Checks the header of a received message against what THIS rank is waiting for; returns the payload view."""
-  head = msg[:HEADER].tolist()
+  head = msg[:HEADER].tolist()   # (one 16-byte device -> host copy: the receiver needs the payload next anyway)
   n = int(np.prod(context_shape))
-  if head[0] != MAGIC or int(head[1]) != song or int(head[2]) != src_rank or int(head[3]) != n:
+  want = [MAGIC, float(song), float(src_rank), float(n)]
+  # compared as floats: a garbage header (NaN, inf, fractions) is a HandoffError like any other mismatch, never a
+  # ValueError / OverflowError out of int()
+  if len(head) != HEADER or any(not (h == w) for h, w in zip(head, want)):
     raise HandoffError('context hand-off out of order: expected (song %d from rank %d, %d values), got header %s'
                        % (song, src_rank, n, head))
   return msg[HEADER:].reshape(context_shape)
@@ -86,13 +90,12 @@ class _Outbox:
     self.pending = []
 
   def post(self, msg, dst: int, group=None, tag: int = 0):
-    dist = _dist()
-    if dist.get_backend(group) == 'nccl':
-      # NCCL / RCCL point-to-point: batched form (one group call per message), the form that cannot interleave with a
-      # concurrent recv on the same communicator in the wrong order
-      works = dist.batch_isend_irecv([dist.P2POp(dist.isend, msg, dst, group)])
-    else:
-      works = [dist.isend(msg, dst=dst, group=group, tag=tag)]
+    # Plain isend on every backend.  On NCCL / RCCL a plain point-to-point call gets a communicator and a stream PER
+    # PEER PAIR, so this rank's send to r+1 and its receive from r-1 are independent; batch_isend_irecv (round 4) puts
+    # both on the group-wide communicator's one stream, where the receive of song j+1 queues behind the still pending
+    # send of song j -- no deadlock, but no overlap either.  NCCL ignores `tag`: the ORDER is enforced by
+    # the header check in unpack_handoff, not by the transport.
+    works = [_dist().isend(msg, dst=dst, group=group, tag=tag)]
     self.pending.append((works, msg))
 
   def drain(self):
@@ -103,12 +106,29 @@ class _Outbox:
 
 
 def _recv(buf, src: int, group=None, tag: int = 0):
+  _dist().recv(buf, src=src, group=group, tag=tag)
+
+
+_warmed = set()
+
+
+def warm_up(group=None, comm_device='cpu'):
+  """One collective over the whole group before the first point-to-point call.  torch's NCCL / RCCL backend creates
+  the group's communicator lazily, and its documentation requires EVERY rank of the group to take part when a
+  point-to-point call is the group's first NCCL call -- but a rank whose chunk is empty neither sends nor receives
+  (chained_predict), which could leave the others waiting in communicator setup.  Every entry point of this module
+  that is called by all ranks starts with this (once per group and process); harmless on gloo."""
   dist = _dist()
-  if dist.get_backend(group) == 'nccl':
-    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, src, group)]):
-      w.wait()
-  else:
-    dist.recv(buf, src=src, group=group, tag=tag)
+  key = id(group) if group is not None else 0
+  if key in _warmed or not dist.is_initialized():
+    return
+  import torch
+  on_nccl = dist.get_backend(group) == 'nccl'
+  t = torch.zeros(1, dtype=torch.float32, device=comm_device if on_nccl else 'cpu')
+  dist.all_reduce(t, group=group)
+  if on_nccl:
+    torch.cuda.synchronize()
+  _warmed.add(key)
 
 
 def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.ndarray],
@@ -131,6 +151,8 @@ def chained_predict(predict_sequence: Callable, segments_tokens: Sequence[np.nda
   """
   import torch
   dev = _on_device(comm_device)
+  if world > 1:
+    warm_up(group, comm_device)   # (every rank calls chained_predict, also those with an empty chunk)
   start, stop = contiguous_chunk(len(segments_tokens), rank, world)
   init_context = None
   if rank > 0 and 0 < start < len(segments_tokens):  # mirrors the sender's condition

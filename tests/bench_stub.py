@@ -68,6 +68,11 @@ class StubInferenceModel:
   def predict_sequence(self, segments_tokens, seed=0, always_mask_context=False, init_context=None,
                        first_segment_index=0, return_timing=False, rng='philox', return_torch=False):
     prev = None if init_context is None else init_context
+    import os
+    # test hook (tests/test_bench_launch.py): the rank named here never returns from the hand-off leg's segments
+    # (seeds >= 100 are that leg's songs) -- the stand-in for a hung point-to-point transport
+    if os.environ.get('MSD_STUB_HANG_RANK') == os.environ.get('RANK') and seed >= 100:
+      time.sleep(3600)
     outs = []
     for i, toks in enumerate(segments_tokens):
       masked = always_mask_context or self.targets_context_length is None

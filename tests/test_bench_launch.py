@@ -47,6 +47,33 @@ def test_plain_command_starts_its_own_ranks(mode):
   assert [r['rank'] for r in seen] == [0, 1] and len({r['pid'] for r in seen}) == 2
   assert len(d['per_rank_seconds']) == 2 and all(t > 0 for t in d['per_rank_seconds'])
   assert abs(max(d['per_rank_seconds']) - d['ms_per_step'] * 3e-3) < 1e-3 * d['ms_per_step'] * 3e-3 + 2e-6   # `value` is over the slowest rank
+  assert d['per_rank_precision'] == ['f16x3', 'f16x3'] and all(r['precision'] == 'f16x3' for r in seen)
+  assert d['config']['precision'] == 'f16x3' and d['config']['precision_requested'] == 'f16x3'
+  if mode == 'replicas':
+    # BASELINE config 4 as a leg of the plain line: the 118-segment workload as a wavefront of songs x 2 segments
+    # (capped at --handoff-max-segments per rank), every rank's idle fraction, finite outputs
+    h4 = d['handoff']
+    assert h4['ok'] is True and h4['mode'] == 'wavefront' and h4['segments_per_song'] == 2
+    assert h4['songs'] == 16 and h4['segments'] == 32 and h4['value'] > 0
+    assert [r['rank'] for r in h4['per_rank']] == [0, 1]
+    assert all(0.0 <= r['idle_fraction'] <= 1.0 and r['busy_seconds'] <= r['seconds'] + 1e-6 for r in h4['per_rank'])
+    assert abs(h4['ideal_efficiency'] - 16 / 17) < 1e-3
+  else:
+    assert 'handoff' not in d
+
+
+def test_a_hung_handoff_leg_still_prints_the_replicas_line():
+  """First contact with RCCL point-to-point must not cost the SCALE record: when the hand-off leg hangs (here: rank 1
+  never returns from its segments), every rank's watchdog ends its process after --handoff-timeout and rank 0 prints
+  the line it already has -- replicas figures intact, `handoff.error` set."""
+  p = run_bench('--gpus', '2', '--steps', '2', '--warmup', '1', '--handoff-timeout', '6', env_extra={'MSD_STUB_HANG_RANK': '1'},
+                timeout=120)
+  lines = json_lines(p.stdout)
+  assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
+  d = lines[0]
+  assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['mode'] == 'replicas'
+  assert d['handoff']['ok'] is False and 'did not finish' in d['handoff']['error']
+  assert d['handoff_check']['ok'] is True      # the probe ran before the leg hung
 
 
 def test_single_rank_needs_no_launcher():

@@ -214,4 +214,7 @@ def test_small_sharp_attention_1000_steps(gain):
         '| Q and P one plane %.3e (x%.2f)' % (gain, floor, errs['default'], errs['default'] / floor, errs['P one plane'],
                                               errs['P one plane'] / floor, errs['Q and P one plane'], errs['Q and P one plane'] / floor))
   assert errs['default'] <= 1.3 * floor and errs['default'] <= 1e-3
-  assert errs['Q and P one plane'] <= 2e-3
+  # the opt-in modes are gated too: north_star's bar for both, and P alone stays float32-class
+  # (measured at gain 4: P one plane x1.10 of the floor, Q and P one plane 4.5e-4)
+  assert errs['P one plane'] <= 1.3 * floor and errs['P one plane'] <= 1e-3
+  assert errs['Q and P one plane'] <= 1e-3
