@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 4   /* 4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
+#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights appended to msd_config.
+                                   4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
                                       NO environment variable.  3: MSD_ERR_RANGE; distinct bfloat16-plane precisions */
 
@@ -153,6 +154,16 @@ typedef struct msd_config {
   int32_t weight_prefetch;        /* producers warm the next GEMM's weights: 0 = the library decides from the model's
                                      size (on when a step streams more than the 256 MB Infinity Cache holds), 1 = on,
                                      2 = off */
+  /* ABI 5 */
+  int32_t dedup_layer0;           /* a CFG step computes decoder layer 0's self-attention block once for both passes
+                                     (they are bit-identical up to the first cross-attention: models/diffusion/models.py:
+                                     373-386): 0 = the library's choice (on), 1 = on, 2 = off (A/B and bitwise tests) */
+  int32_t cross_key_split;        /* blocks that share the key axis of one (head, query tile) of the decoder's
+                                     cross-attention: 0 = the library chooses per msd_encode from the segment's key
+                                     count and the batch, else 1, 2, 4 or 8 */
+  int32_t keep_raw_weights;       /* 0 = msd_finalize_weights frees the float32 staging copy of every matrix it has
+                                     packed into operand planes (1.5 GB of 1.65 at base_with_context); 1 = keep them
+                                     (msd_set_weight + msd_finalize_weights can then be repeated on this handle) */
 } msd_config;
 
 const char* msd_version(void);

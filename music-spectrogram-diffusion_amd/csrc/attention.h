@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 }
 
 // Finish a key-split attention: out[row][head*64 + d] = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m)
-// KS = the split count as a compile-time constant (2, 3, 4; 0 = run-time loop).  With a run-time count the two loops
+// KS = the split count as a compile-time constant (2, 4, 8; 0 = run-time loop).  With a run-time count the two loops
 // over the splits stayed rolled, each iteration waiting for its own loads: six dependent L2 round trips in a kernel
 // that moves 4 MB -- 2.7 of its 5.0 us (profiles/r03p_phase_times_b1.txt).  Unrolled, the (m, l) pairs and the O rows
 // of every split are in flight together before anything is computed; the sums still run in split order (same bits).
@@ -531,6 +531,8 @@ inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, 
     const dim3 mg((items + 255) / 256), mb(256);
     const unsigned inv_heads = heads > 1 ? (unsigned)((0x100000000ull + (unsigned)heads - 1) / (unsigned)heads) : 0u;
     if (p.ksplit == 4) hipLaunchKernelGGL((attention_merge_kernel<NP, 4>), mg, mb, 0, stream, p, heads, inv_heads);
+    else if (p.ksplit == 2) hipLaunchKernelGGL((attention_merge_kernel<NP, 2>), mg, mb, 0, stream, p, heads, inv_heads);
+    else if (p.ksplit == 8) hipLaunchKernelGGL((attention_merge_kernel<NP, 8>), mg, mb, 0, stream, p, heads, inv_heads);
     else hipLaunchKernelGGL((attention_merge_kernel<NP, 0>), mg, mb, 0, stream, p, heads, inv_heads);
   }
   return hipGetLastError();

@@ -867,7 +867,11 @@ struct EpiResidual {
 //   x += acc ;  ssq[m][col/32] = sum over each 32-column group of x^2 ;
 //   y = x (.) g  as bf16 planes, g = g_lo for rows < split_row, g_hi otherwise
 //   (g pointer = base + step * step_stride; a null base skips y for that row range).
-template <int NP>
+// DUP (layer 0 of a CFG step): the launch runs on the conditional pass's rows only and every row r is
+// ALSO written as row r + dup_rows -- the unconditional pass starts from the same z, the same FiLM and the same
+// self-attention (models/diffusion/models.py:373-386, network.py:174-193), so up to here its rows are bit-for-bit the
+// conditional ones: x and ssq are copied, y[r] = x (.) g_lo and y[r + dup_rows] = x (.) g_hi (split_row is not used).
+template <int NP, bool DUP = false>
 struct EpiResidualNorm {
   float* x;
   int ldx;
@@ -878,6 +882,7 @@ struct EpiResidualNorm {
   const float* g_hi; int g_hi_stride;
   int split_row;
   const int* step_ptr;
+  int dup_rows = 0;   // DUP only: distance to the second copy of a row (= rows of one pass)
   // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB]
   template <int BN> static constexpr bool narrow() { return BN == 32 || BN == 48; }
   template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 2048 : 0; }
@@ -907,6 +912,7 @@ struct EpiResidualNorm {
   __device__ void run48(float* s0, int m0, int n0, int tid, const char* aux, SatFlag sf) const {
     constexpr int BN = 48;
     static_assert(BM * 8 == 256, "one 8-lane group per row");
+    static_assert(!DUP, "the duplicating form runs on 32-column (or batched 96-column) tiles");
     typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
     lds_cf32x4 xs = (lds_cf32x4)(aux);
     lds_cf32x4 gl = (lds_cf32x4)(aux + BM * BN * 4), gh = (lds_cf32x4)(aux + BM * BN * 4 + 1024);
@@ -973,13 +979,28 @@ struct EpiResidualNorm {
       sq += __shfl_xor(sq, 1, 64);   // 4 consecutive lanes = one 32-column group of one row
       sq += __shfl_xor(sq, 2, 64);
       if ((item & 3) == 0) ssq[(size_t)row * tiles + col / 32] = sq;
-      const bool lo_rows = row < split_row;
-      if (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr)) {
-        float4 g0, g1;
-        LG(lo_rows, n, col, g0, g1);
-        v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
-        v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
-        store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
+      if constexpr (DUP) {
+        const size_t row2 = (size_t)row + dup_rows;
+        float4* px2 = reinterpret_cast<float4*>(x + row2 * ldx + col);
+        px2[0] = make_float4(v[0], v[1], v[2], v[3]);
+        px2[1] = make_float4(v[4], v[5], v[6], v[7]);
+        if ((item & 3) == 0) ssq[row2 * tiles + col / 32] = sq;
+        float4 g0, g1, h0, h1;
+        LG(true, n, col, g0, g1);
+        LG(false, n, col, h0, h1);
+        const float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w, v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
+        const float u[8] = {v[0] * h0.x, v[1] * h0.y, v[2] * h0.z, v[3] * h0.w, v[4] * h1.x, v[5] * h1.y, v[6] * h1.z, v[7] * h1.w};
+        store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
+        store_h16x8<NP>(y, row2 * ldx + col, u, rc);
+      } else {
+        const bool lo_rows = row < split_row;
+        if (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr)) {
+          float4 g0, g1;
+          LG(lo_rows, n, col, g0, g1);
+          v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
+          v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
+          store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
+        }
       }
     };
     if (pre) {   // operands prefetched into the aux LDS region: explicit LDS pointers (ds_read)
@@ -1004,7 +1025,7 @@ struct EpiResidualNorm {
       const float* glo = g_lo ? g_lo + (size_t)step * g_lo_stride : nullptr;
       const float* ghi = g_hi ? g_hi + (size_t)step * g_hi_stride : nullptr;
       constexpr int ITEMS = BM * BN / 8, PER = (ITEMS + 255) / 256;
-      f32x4 xa[PER], xb[PER], ga[PER], gb[PER];
+      f32x4 xa[PER], xb[PER], ga[PER], gb[PER], ha[DUP ? PER : 1], hb[DUP ? PER : 1];
 #pragma unroll
       for (int it = 0; it < PER; ++it) {
         const int item = tid + it * 256;
@@ -1013,10 +1034,15 @@ struct EpiResidualNorm {
           const int row = m0 + m, col = n0 + n;
           const f32x4* px = reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + col);
           xa[it] = px[0]; xb[it] = px[1];
-          const float* g = row < split_row ? glo : ghi;
-          if (g != nullptr) {
-            ga[it] = *reinterpret_cast<const f32x4*>(g + col);
-            gb[it] = *reinterpret_cast<const f32x4*>(g + col + 4);
+          if constexpr (DUP) {   // both gain rows of every item (the launcher sets both)
+            ga[it] = *reinterpret_cast<const f32x4*>(glo + col); gb[it] = *reinterpret_cast<const f32x4*>(glo + col + 4);
+            ha[it] = *reinterpret_cast<const f32x4*>(ghi + col); hb[it] = *reinterpret_cast<const f32x4*>(ghi + col + 4);
+          } else {
+            const float* g = row < split_row ? glo : ghi;
+            if (g != nullptr) {
+              ga[it] = *reinterpret_cast<const f32x4*>(g + col);
+              gb[it] = *reinterpret_cast<const f32x4*>(g + col + 4);
+            }
           }
         }
       }
@@ -1027,7 +1053,10 @@ struct EpiResidualNorm {
         if (ITEMS % 256 == 0 || item < ITEMS)
           body(item,
                [&](int, int, float4*, float4& a, float4& b2) { a = f4(xa[it]); b2 = f4(xb[it]); },
-               [&](bool, int, int, float4& g0, float4& g1) { g0 = f4(ga[it]); g1 = f4(gb[it]); });
+               [&](bool lo, int, int, float4& g0, float4& g1) {
+                 if (DUP && !lo) { g0 = f4(ha[DUP ? it : 0]); g1 = f4(hb[DUP ? it : 0]); }
+                 else { g0 = f4(ga[it]); g1 = f4(gb[it]); }
+               });
       }
     }
     rc.commit(sf.p, sf.tag);

@@ -2,9 +2,8 @@
 // weight store + packing, step-indexed tables, encoder, the per-step kernel chain,
 // hipGraph capture/replay of one DDPM step, profiling.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cctype>
-#include <cstdio>
-
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -152,11 +151,13 @@ struct msd_model {
   int *d_tokens = nullptr, *d_pos = nullptr, *d_nkeys_enc = nullptr;
   float *ctx_scaled = nullptr, *ctx_full = nullptr;
 
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_batch = 0;
+  // instantiated step graphs, one set per (batch, key split of each cross-attention module): the split is chosen per
+  // msd_encode from the segment's key count (cross_split), and a graph bakes its grids in
+  struct StepGraphs { int batch = 0, ks[2] = {0, 0}; hipGraphExec_t exec = nullptr, exec1 = nullptr; };
+  std::vector<StepGraphs> graphs;
   int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
-  hipGraphExec_t graph_exec1 = nullptr;   // single-step graph for N mod graph_steps
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
+  bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
   // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
@@ -493,11 +494,13 @@ hipError_t prepare_gemms() {
     PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiQKV<NP>) PREP(128, 128, 2, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreH16<NP>)
+    { using EpiDup = EpiResidualNorm<NP, true>; PREP(128, 96, 2, EpiDup) }
     PREP(32, kWide48, 4, EpiResidualNorm<NP>)
   }
   PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreH16<NP>)
   PREP(32, 32, 4, EpiStoreF32) PREP(32, 32, 4, EpiInProj<NP>)
   PREP(64, 32, kTallNS, EpiResidual) PREP(64, 32, kTallNS, EpiResidualNorm<NP>)
+  { using EpiDup = EpiResidualNorm<NP, true>; PREP(32, 32, 4, EpiDup) PREP(64, 32, kTallNS, EpiDup) }
   PREP(64, 64, 3, EpiStoreF32)
 #undef PREP
   return e;
@@ -915,15 +918,43 @@ int encode_impl(msd_model* m, int batch, const int32_t* tokens_h, const float* c
 // several songs per handle the (head, query group, song) blocks already cover the CUs, and every split costs a
 // partial round trip + the merge launch: split only as far as ~192 blocks need.
 
-inline int cross_ksplit_for(const msd_model* m, int batch) {
-  const int blocks = m->H * (m->T / 64) * batch;
-  int ks = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
-  return ks < m->cross_ksplit ? ks : m->cross_ksplit;
+// ... and as far as the segment's key axis pays for: a block of a split-s launch sees n_keys / (128 s) ring stages.
+// Module e's key region and the most keys any song of the encoded batch has there:
+inline int cross_region(const msd_model* m, int e) {
+  return (e + 1 < m->n_cross ? m->key_off[e + 1] : m->S_pad) - m->key_off[e];
+}
+inline int cross_keys_max(const msd_model* m, int batch, int e) {
+  int k = 0;
+  for (int b = 0; b < batch && b < m->Bmax; ++b) k = std::max(k, m->h_nkeys_cross[(size_t)e * m->Bmax + b]);
+  return k;
+}
+// The key split of cross-attention module e for the batch msd_encode prepared (msd_config.cross_key_split = 0), or the
+// caller's choice; always a power of two within the workspace (m->cross_ksplit) and the region's stage count.
+inline int cross_split(const msd_model* m, int batch, int e) {
+  const int region = cross_region(m, e), stages = std::max(1, region / kAttStageKeys);
+  int want;
+  if (m->cfg.cross_key_split > 0) {
+    want = m->cfg.cross_key_split;
+  } else {
+    const int blocks = m->H * (m->T / 64) * batch;
+    want = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
+    // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
+    const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1);
+    want = std::min(want, cap);
+  }
+  want = std::min(want, std::min(m->cross_ksplit, stages));
+  int ks = 1;
+  while (ks * 2 <= want) ks *= 2;
+  return ks;
 }
 
 template <int NP>
-void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
-  // P passes of `batch` songs: rows [0, BT) are the conditional pass when `cond0`, rows [BT, 2 BT) the unconditional one
+void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
+  // P passes of `batch` songs: rows [0, BT) are the conditional pass when `cond0`, rows [BT, 2 BT) the unconditional one.
+  // `dedup0` (a CFG step: P == 2, cond0; the input projection wrote pass 0 only): S5 -- up to layer 0's first
+  // cross-attention both passes hold the same rows (same z, same FiLM, same self-attention: models.py:373-386,
+  // network.py:174-193), so layer 0's QKV / self-attention / attention-out run on BT rows and the attention-out
+  // epilogue writes every row twice (gemm_h16.h EpiResidualNorm<NP, true>).  Exact: bit-identical to the 2 BT-row form.
   msd_model* m = c.m;
   const int D = m->D, J = m->J, F = m->F, T = m->T;
   const int BT = batch * T, M = P * BT;
@@ -957,16 +988,18 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     // wave of its own): QKV -> attention-out . self-attention -> cross-q (or MLP-in on an unconditional pass) .
     // cross-q -> cross-out . cross-attention -> MLP-in . MLP-in -> MLP-out . MLP-out -> next layer's QKV
     const bool last_layer = (l + 1 == m->Ld);
+    const bool dup = dedup0 && l == 0;          // this layer's self-attention block runs on one pass's rows
+    const int Ms = dup ? BT : M, Ps = dup ? 1 : P;
     {
       const EpiQKV<NP> eq = qkv_epi(l);
       WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
-      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, M, 3 * J, D, eq, eq.v_start, &pf);
+      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, Ms, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     {
       WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
-                    (size_t)J * T, ao, J, nkeys_self, T, m->H, P * batch, 1, 0, &pf);
+                    (size_t)J * T, ao, J, nkeys_self, T, m->H, Ps * batch, 1, 0, &pf);
     }
     // out-projection + residual; produces y for the cross-attention norm (conditional rows:
     // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
@@ -976,6 +1009,13 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
     er.g_lo = cond0 ? w.ln_cross : g_tab(2 * l + 1); er.g_lo_stride = cond0 ? 0 : slots * D;
     er.g_hi = g_tab(2 * l + 1); er.g_hi_stride = slots * D;
     er.split_row = cond0 ? BT : 0;
+    if (dup) {   // rows [0, BT) computed once, written as both passes: y[r] for the cross-attention norm, y[r + BT] for the MLP norm
+      EpiResidualNorm<NP, true> ed;
+      ed.x = x; ed.ldx = D; ed.y[0] = y.p[0]; ed.y[1] = y.p[NP - 1]; ed.ssq = ssq; ed.tiles = tiles; ed.step_ptr = m->d_step;
+      ed.g_lo = er.g_lo; ed.g_lo_stride = er.g_lo_stride; ed.g_hi = er.g_hi; ed.g_hi_stride = er.g_hi_stride;
+      ed.split_row = 0; ed.dup_rows = BT;
+      gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, BT, D, J, ed);
+    } else
     gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
@@ -996,10 +1036,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
         Planes vt;
         vt.p[0] = m->vtc.p[0] + loff + r0;
         vt.p[1] = NP == 2 ? m->vtc.p[1] + loff + r0 : nullptr;
-        const int region = (e + 1 < m->n_cross ? m->key_off[e + 1] : m->S_pad) - m->key_off[e];
-        // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
-        const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1), want = cross_ksplit_for(m, batch);
-        const int ks = want < cap ? want : cap;
+        const int region = cross_region(m, e), ks = cross_split(m, batch, e);
         const bool warm_mlp_in = e + 1 == m->n_cross;
         const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
@@ -1053,7 +1090,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0) {
 }
 
 template <int NP>
-void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {
+void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {   // P: passes whose rows are written (dedup0: 1)
   msd_model* m = c.m;
   const int BT = batch * m->T;
   EpiInProj<NP> ei;
@@ -1075,8 +1112,10 @@ template <int NP>
 void enqueue_step(Ctx& c, int batch) {
   msd_model* m = c.m;
   const int P = m->passes;
-  in_proj<NP>(c, batch, P, /*publish_step=*/true);
-  decoder_layers<NP>(c, batch, P, true);
+  // S5: a CFG step computes layer 0's self-attention block once for both passes
+  const bool dedup0 = P == 2 && m->dedup_layer0;
+  in_proj<NP>(c, batch, dedup0 ? 1 : P, /*publish_step=*/true);
+  decoder_layers<NP>(c, batch, P, true, dedup0);
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
@@ -1109,7 +1148,7 @@ void set_func_attrs() {
 extern "C" {
 
 const char* msd_version(void) {
-  static const std::string v = std::string("msd_amd 0.5.0 (gfx950, abi 4, ") + kPlaneName + ")";
+  static const std::string v = std::string("msd_amd 0.6.0 (gfx950, abi 5, ") + kPlaneName + ")";
   return v.c_str();
 }
 
@@ -1156,6 +1195,10 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->attn_p_planes < 0 || cfg->attn_p_planes > 2) return bad("attn_p_planes must be 0 (library default), 1 or 2");
   if (cfg->graph_steps < 0 || cfg->graph_steps > 64) return bad("graph_steps must be in [0, 64] (0 = library default)");
   if (cfg->weight_prefetch < 0 || cfg->weight_prefetch > 2) return bad("weight_prefetch must be 0 (by model size), 1 (on) or 2 (off)");
+  if (cfg->dedup_layer0 < 0 || cfg->dedup_layer0 > 2) return bad("dedup_layer0 must be 0 (library default), 1 (on) or 2 (off)");
+  if (cfg->cross_key_split != 0 && cfg->cross_key_split != 1 && cfg->cross_key_split != 2 && cfg->cross_key_split != 4 &&
+      cfg->cross_key_split != 8) return bad("cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8");
+  if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1169,6 +1212,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->passes = (cfg->cfg_weight != 1.0f) ? 2 : 1;
   if (cfg->graph_steps > 0) m->graph_steps = cfg->graph_steps;
   if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
+  m->dedup_layer0 = cfg->dedup_layer0 != 2;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-
@@ -1208,7 +1252,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(palloc(m, &m->zp, (size_t)m->Bmax * T * m->ND));
   TRY(dalloc(m, &m->ssq, Mmax * (D / kNarrowTile)));
   // cross-attention key split: enough blocks for the whole chip when the key axis is long
-  m->cross_ksplit = m->S_pad >= 1024 ? 4 : (m->S_pad >= 512 ? 2 : 1);
+  m->cross_ksplit = m->S_pad >= 1024 ? 8 : (m->S_pad >= 512 ? 4 : (m->S_pad >= 256 ? 2 : 1));   // workspace bound
   TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
   TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
   TRY(palloc(m, &m->h, Mmax * D));
@@ -1263,8 +1307,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
 
 void msd_destroy(msd_model* m) {
   if (!m) return;
-  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-  if (m->graph_exec1) (void)hipGraphExecDestroy(m->graph_exec1);
+  (void)msd_reset_graph(m);
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -1294,6 +1337,9 @@ int msd_set_weight(msd_model* m, const char* name, const float* data, const int6
   if (!ok)
     return fail(m, MSD_ERR_SHAPE_MISMATCH, "weight '%s': expected [%lld,%lld] (ndim %d)", name,
                 (long long)w.shape[0], (long long)w.shape[1], w.ndim);
+  if (!w.dev)
+    return fail(m, MSD_ERR_BAD_STATE, "weight '%s': msd_finalize_weights has run and freed its staging copy (weights are "
+                "loaded once per handle; create a new model)", name);
   HIP_TRY(m, hipMemcpy(w.dev, data, (size_t)w.numel() * sizeof(float), hipMemcpyDefault));
   w.set = true;
   m->finalized = false;
@@ -1372,6 +1418,20 @@ int msd_finalize_weights(msd_model* m, void* stream) {
                   "a projection weight has magnitude %g: the %s of this build hold |w| < %g (the bfloat16-plane build, "
                   "libmsd_amd_bf16.so / precision 'bf16x3', has no such limit)",
                   (double)top, kPlaneName, (double)(kPlaneMax / kWScale));
+  }
+  if (!m->cfg.keep_raw_weights) {
+    // The float32 staging copy of every matrix that now lives in operand planes / tables has no reader left (finalize
+    // runs once per handle): 1.5 GB of the 1.65 GB at base_with_context.  What run time still reads from the raw store
+    // stays: the 1-D norm scales, the embedding / position tables and the context encoder's fp32 input projection.
+    std::vector<const float*> keep = {m->tok_emb, m->tok_pos, m->w_ctx_in, m->ctx_pos, m->dec_pos};
+    for (auto& w : m->weights) {
+      if (w.ndim != 2 || !w.dev || std::find(keep.begin(), keep.end(), w.dev) != keep.end()) continue;
+      auto it = std::find(m->allocs.begin(), m->allocs.end(), static_cast<void*>(w.dev));
+      if (it != m->allocs.end()) m->allocs.erase(it);
+      (void)hipFree(w.dev);
+      w.dev = nullptr;
+    }
+    m->w_spec_out = m->w_in_proj = nullptr;   // (packed: w_out_g / w_out_p, w_in_p)
   }
   m->finalized = true;
   return MSD_OK;
@@ -1477,20 +1537,28 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
     if (ie != hipSuccess) { *out = nullptr; return fail(m, MSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
     return MSD_OK;
   };
-  if (!m->graph_exec || m->graph_batch != batch) {
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
-    int rc = capture(m->graph_steps, &m->graph_exec);
+  // the graphs of this (batch, key splits) -- the splits follow the key counts msd_encode saw
+  const int ks0 = cross_split(m, batch, 0);
+  const int ks1 = m->n_cross > 1 ? cross_split(m, batch, 1) : 0;
+  msd_model::StepGraphs* g = nullptr;
+  for (auto& e : m->graphs)
+    if (e.batch == batch && e.ks[0] == ks0 && e.ks[1] == ks1) g = &e;
+  if (!g) {
+    if (m->graphs.size() >= 8) (void)msd_reset_graph(m);   // (a handle that cycles through more shapes than that re-captures)
+    msd_model::StepGraphs ng;
+    ng.batch = batch; ng.ks[0] = ks0; ng.ks[1] = ks1;
+    int rc = capture(m->graph_steps, &ng.exec);
     if (rc) return rc;
     if (m->graph_steps > 1 && m->N % m->graph_steps) {
-      rc = capture(1, &m->graph_exec1);
-      if (rc) return rc;
+      rc = capture(1, &ng.exec1);
+      if (rc) { (void)hipGraphExecDestroy(ng.exec); return rc; }
     }
-    m->graph_batch = batch;
+    m->graphs.push_back(ng);
+    g = &m->graphs.back();
   }
-  for (int i = 0; i < m->N / m->graph_steps; ++i) HIP_TRY(m, hipGraphLaunch(m->graph_exec, s));
+  for (int i = 0; i < m->N / m->graph_steps; ++i) HIP_TRY(m, hipGraphLaunch(g->exec, s));
   for (int i = 0; i < m->N % m->graph_steps; ++i)
-    HIP_TRY(m, hipGraphLaunch(m->graph_steps > 1 ? m->graph_exec1 : m->graph_exec, s));
+    HIP_TRY(m, hipGraphLaunch(m->graph_steps > 1 ? g->exec1 : g->exec, s));
   hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->z, out_dev,
                      (int)n, m->cfg.feature_min, m->cfg.feature_max);
   HIP_TRY(m, hipGetLastError());
@@ -1501,9 +1569,11 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
 
 int msd_reset_graph(msd_model* m) {
   if (!m) return MSD_ERR_INVALID_ARGUMENT;
-  if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-  if (m->graph_exec1) { (void)hipGraphExecDestroy(m->graph_exec1); m->graph_exec1 = nullptr; }
-  m->graph_batch = 0;
+  for (auto& e : m->graphs) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.exec1) (void)hipGraphExecDestroy(e.exec1);
+  }
+  m->graphs.clear();
   return MSD_OK;
 }
 

@@ -76,7 +76,8 @@ class _ModelInfo:
 
 def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec,
                       batch_size: int, precision: str, attention_query_planes=None, graph_steps: int = 0,
-                      weight_prefetch: Optional[bool] = None) -> native.MsdConfig:
+                      weight_prefetch: Optional[bool] = None, dedup_layer0: Optional[bool] = None,
+                      cross_key_split: int = 0, keep_raw_weights: bool = False) -> native.MsdConfig:
   t5, d = spec.t5, spec.diffusion
   # Everything the kernels fix by construction is validated here with the
   # reference's own error type (ValueError; msd_amd.h msd_config comment).
@@ -161,6 +162,11 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
     raise ValueError('graph_steps must be in [0, 64] (0 = library default)')
   cfg.graph_steps = int(graph_steps)
   cfg.weight_prefetch = 0 if weight_prefetch is None else (1 if weight_prefetch else 2)
+  cfg.dedup_layer0 = 0 if dedup_layer0 is None else (1 if dedup_layer0 else 2)
+  if int(cross_key_split) not in (0, 1, 2, 4, 8):
+    raise ValueError('cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8')
+  cfg.cross_key_split = int(cross_key_split)
+  cfg.keep_raw_weights = int(bool(keep_raw_weights))
   return cfg
 
 
@@ -197,7 +203,8 @@ class InferenceModel(object):
   def __init__(self, checkpoint_path, gin_config: Union[str, config_lib.ModelSpec],
                batch_size: int = 1, precision: str = 'f16x3', device: Optional[int] = None,
                range_fallback: bool = True, attention_query_planes=None, graph_steps: int = 0,
-               weight_prefetch: Optional[bool] = None):
+               weight_prefetch: Optional[bool] = None, dedup_layer0: Optional[bool] = None,
+               cross_key_split: int = 0, keep_raw_weights: bool = False):
     """Args mirror inference.py:71-88.
 
     gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
@@ -212,6 +219,13 @@ class InferenceModel(object):
       the softmax weights (in P.V), or a (q_planes, p_planes) pair.  The memory side (K, V) always keeps hi + lo.
     graph_steps: DDPM steps captured per hipGraph (0 = the library's choice, 8).
     weight_prefetch: None = the library decides from the model's size; True / False force it.
+    dedup_layer0: a CFG step computes decoder layer 0's self-attention block once for both passes (exact: they are
+      bit-identical up to the first cross-attention, models/diffusion/models.py:373-386); None = the library's choice
+      (on), False turns it off (A/B and bitwise tests).
+    cross_key_split: blocks sharing the key axis of one (head, query tile) of the decoder's cross-attention; 0 = the
+      library chooses per segment from its key count, else 1, 2, 4 or 8.
+    keep_raw_weights: keep the float32 staging copies of the packed matrices on the device (default: freed after
+      packing -- 1.5 GB per handle at base_with_context).
     range_fallback: what to do when an activation leaves the range of the half planes (|x| > 65504; the
       library detects it and fails the call with native.RangeError -- the reference is float32 and has no such
       limit): True (default) switches this model to 'bf16x3' (bfloat16 planes: float32's exponent range, twice
@@ -232,6 +246,7 @@ class InferenceModel(object):
     self.range_fallback = bool(range_fallback)
     self.attention_query_planes = attention_query_planes
     self.graph_steps, self.weight_prefetch = graph_steps, weight_prefetch
+    self.dedup_layer0, self.cross_key_split, self.keep_raw_weights = dedup_layer0, cross_key_split, keep_raw_weights
 
     self.sequence_length = dict(spec.task_feature_lengths)
     self.inputs_length = self.sequence_length['inputs']
@@ -297,7 +312,8 @@ class InferenceModel(object):
         else:
           params, self._step = _load_checkpoint(self.checkpoint_path, self.spec)
         cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision,
-                                self.attention_query_planes, self.graph_steps, self.weight_prefetch)
+                                self.attention_query_planes, self.graph_steps, self.weight_prefetch,
+                                self.dedup_layer0, self.cross_key_split, self.keep_raw_weights)
         nm = native.NativeModel(cfg)   # the library build (plane format) follows from cfg.precision
         self._stream = torch.cuda.Stream(device=self.device)
         nm.load_weights(params, stream=self._stream.cuda_stream)

@@ -26,7 +26,7 @@ MSD_PREC_F16 = 0      # one IEEE-half plane per operand
 MSD_PREC_F16X3 = 1    # hi + lo half planes, three MFMAs per product (the parity mode, the default)
 MSD_PREC_BF16 = 2     # one bfloat16 plane                       } libmsd_amd_bf16.so; msd_create of the other
 MSD_PREC_BF16X3 = 3   # hi + lo bfloat16 planes                  } build answers MSD_ERR_UNSUPPORTED
-ABI_VERSION = 4        # MSD_AMD_ABI_VERSION of include/msd_amd.h (tests/test_abi.py)
+ABI_VERSION = 5        # MSD_AMD_ABI_VERSION of include/msd_amd.h (tests/test_abi.py)
 MSD_SAMPLER_DDPM = 0
 MSD_SAMPLER_DDIM = 1
 MAX_KERNEL_CLASSES = 16
@@ -73,7 +73,7 @@ MODEL_OUTPUTS = {'eps': MSD_OUTPUT_EPS, 'x0': MSD_OUTPUT_X0, 'v': MSD_OUTPUT_V}
 
 
 class MsdConfig(ctypes.Structure):
-  """msd_config of include/msd_amd.h (ABI 4), field for field."""
+  """msd_config of include/msd_amd.h (ABI 5), field for field."""
   _fields_ = [(n, ctypes.c_int32) for n in (
       'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
       'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
@@ -87,8 +87,13 @@ class MsdConfig(ctypes.Structure):
       ('train_schedule_start', ctypes.c_float), ('train_schedule_stop', ctypes.c_float),
       ('train_schedule_num_steps', ctypes.c_int32), ('cross_attend_sum', ctypes.c_int32),
       ('attn_q_planes', ctypes.c_int32), ('attn_p_planes', ctypes.c_int32), ('graph_steps', ctypes.c_int32),
-      ('weight_prefetch', ctypes.c_int32)]
+      ('weight_prefetch', ctypes.c_int32),
+      ('dedup_layer0', ctypes.c_int32), ('cross_key_split', ctypes.c_int32), ('keep_raw_weights', ctypes.c_int32)]
 
+
+# msd_config only ever grows at its end, so an OLDER library can be driven by passing it the struct size it knows
+# (same-box A/B of a previous round's binary through MSD_AMD_LIB: tools/ab/); the newer fields are then simply not seen.
+ABI_STRUCT_SIZES = {4: MsdConfig.weight_prefetch.offset + 4, 5: ctypes.sizeof(MsdConfig)}
 
 _libs = {}
 
@@ -128,8 +133,10 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
                                % (LIB_PATH, ABI_VERSION))
     lib.msd_version.restype = ctypes.c_char_p
     ver = lib.msd_version() or b''
-    if ('abi %d' % ABI_VERSION).encode() not in ver:
-      raise NativeLibraryError('MSD_AMD_LIB=%s is %r: this package binds ABI %d (msd_config layout)' % (LIB_PATH, ver, ABI_VERSION))
+    lib._msd_abi = next((a for a in ABI_STRUCT_SIZES if ('abi %d' % a).encode() in ver), None)
+    if lib._msd_abi is None:
+      raise NativeLibraryError('MSD_AMD_LIB=%s is %r: this package binds ABI %d (and drives ABI %s through their msd_config size)'
+                               % (LIB_PATH, ver, ABI_VERSION, sorted(set(ABI_STRUCT_SIZES) - {ABI_VERSION})))
   c = ctypes
   vp, i32, i64, u64, u32 = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_uint32
   lib.msd_version.restype = c.c_char_p
@@ -206,7 +213,7 @@ class NativeModel:
     self.planes = planes
     self.cfg = cfg
     self.handle = ctypes.c_void_p()
-    cfg.struct_size = ctypes.sizeof(MsdConfig)
+    cfg.struct_size = ABI_STRUCT_SIZES[getattr(self.lib, '_msd_abi', None) or ABI_VERSION]
     rc = self.lib.msd_create(ctypes.byref(cfg), ctypes.byref(self.handle))
     if rc != 0:
       msg = self.lib.msd_last_error(self.handle).decode() if self.handle else 'invalid config'
@@ -367,7 +374,7 @@ def _op_check(rc, what):
 def op_sampler_step(cfg: MsdConfig, step_index: int, z, out_cond, out_uncond, noise, z_out, stream: int = 0):
   """One sampler update (msd_op_sampler_step).  Tensors: float32 device tensors of equal numel."""
   lib = load()
-  cfg.struct_size = ctypes.sizeof(MsdConfig)
+  cfg.struct_size = ABI_STRUCT_SIZES[getattr(lib, '_msd_abi', None) or ABI_VERSION]
   _op_check(lib.msd_op_sampler_step(ctypes.byref(cfg), step_index, _ptr(z), _ptr(out_cond), _ptr(out_uncond),
                                     _ptr(noise), _ptr(z_out), z.numel(), stream), 'msd_op_sampler_step')
 

@@ -20,7 +20,7 @@ def test_phase_stamps_are_compiled_out_of_the_product():
   """The per-block phase stamps live in the sources behind MSD_TIMESTAMPS (round 4: no more patch file to keep in step
   with the tree); every stamp macro expands to NOTHING unless a debug build defines it, and the built product library
   has neither the table nor its read-back entry point."""
-  text = open(os.path.join(CSRC, 'gemm_h16.h')).read()
+  text = open(os.path.join(CSRC, 'phase_stamps.h')).read()   # (round 5: the stamp macros have a header of their own)
   off = text[text.index('#else', text.index('#if MSD_TIMESTAMPS')):]
   off = off[:off.index('#endif')]
   macros = [l for l in off.splitlines() if l.startswith('#define MSD_TS')]

@@ -335,11 +335,13 @@ def test_rng_jax_mode_uses_reference_draws(tiny_ctx):
     model.predict(batch, rng='mt19937')
 
 
+@pytest.mark.parametrize('split', [0, 1, 2, 4, 8])
 @pytest.mark.parametrize('valid', [1, 130, 1022])
-def test_key_split_cross_attention_edge_lengths(valid):
-  """inputs 1024 + context 64 -> S_pad >= 1024 -> the key-split cross-attention (4 blocks per query
-  group + merge).  Key counts at the extremes: blocks with NO stage of their own (1 valid token, with
-  and without context keys), a ragged last stage, a full key axis.  Single decoder passes against the
+def test_key_split_cross_attention_edge_lengths(valid, split):
+  """inputs 1024 + context 64 -> S_pad >= 1024 -> the key-split cross-attention (`split` blocks per query
+  group + merge; 0 = the library's per-segment choice, the others through msd_config.cross_key_split: every split the
+  launcher can choose is tested, round 5).  Key counts at the extremes: blocks with NO stage of their own (1 valid
+  token, with and without context keys), a ragged last stage, a full key axis.  Single decoder passes against the
   float64 oracle, elementwise (a short sampling chain would only add its own chaos, helpers.py)."""
   import dataclasses
   import torch
@@ -347,7 +349,7 @@ def test_key_split_cross_attention_edge_lengths(valid):
   base = msd_amd.config.preset('tiny_context', num_steps=3)
   spec = dataclasses.replace(base, task_feature_lengths={'inputs': 1024, 'targets': 64, 'targets_context': 64})
   params = msd_amd.synthetic.init_params(spec, 6, norm_scale_jitter=0.1)
-  model = msd_amd.InferenceModel(params, spec, **helpers.ALL_PLANES)
+  model = msd_amd.InferenceModel(params, spec, cross_key_split=split, **helpers.ALL_PLANES)
   nm = model._get_native()
   cfg, dc = helpers.oracle_configs(spec)
   z = np.random.default_rng(0).standard_normal((1, 64, 128)).astype(np.float32)
@@ -537,3 +539,55 @@ def test_base_size_decoder_pass_does_not_depend_on_the_batch():
       rel = np.abs(outs[B, step][0] - ref).max() / np.abs(ref).max()
       print('base size, %d songs, step %d: max rel diff to the one-song pass %.2e' % (B, step, rel))
       assert rel < 2e-5, (B, step, rel)
+
+
+@pytest.mark.parametrize('preset,steps', [('tiny_context', 8), ('small', 3)])
+def test_layer0_dedup_is_bit_identical(preset, steps):
+  """S5 (round 5): in a CFG step decoder layer 0's QKV / self-attention / attention-out run on the conditional pass's
+  rows only and the attention-out epilogue writes every row twice -- both passes hold the same rows up to the first
+  cross-attention (models/diffusion/models.py:373-386, network.py:174-193).  Exact by construction: the sampled
+  segment is BIT-identical with the shortcut on (library default) and off (msd_config.dedup_layer0 = 2), also with two
+  songs per handle; and both match the oracle like every other run."""
+  from oracle import philox
+  spec = msd_amd.config.preset(preset, num_steps=steps)
+  params = msd_amd.synthetic.init_params(spec, 3, norm_scale_jitter=0.1)
+  t = spec.task_feature_lengths['targets']
+  for nb in (1, 2):
+    batch = helpers.make_batch(spec, batch=nb, ctx_mask='ones') if spec.has_context else \
+        {'encoder_input_tokens': np.concatenate([msd_amd.synthetic.segment_tokens(spec, 40 + b) for b in range(nb)], 0)}
+    init_z, noise = philox.segment_noise((nb, t, 128), steps, seed=5, segment=0)
+    outs = []
+    for dedup in (None, False):
+      model = msd_amd.InferenceModel(params, spec, batch_size=nb, dedup_layer0=dedup, **helpers.ALL_PLANES)
+      got, _ = model.predict(batch, init_z=init_z, noise=noise)
+      outs.append(np.asarray(got))
+      del model
+    assert np.array_equal(outs[0], outs[1]), (preset, nb, np.abs(outs[0] - outs[1]).max())
+    assert np.isfinite(outs[0]).all()
+
+
+def test_staging_copies_of_packed_weights_are_freed():
+  """msd_finalize_weights frees the float32 staging copy of every matrix it packed (round 5: 1.5 of 1.65 GB per handle
+  at base_with_context; msd_config.keep_raw_weights = 1 keeps them): the device memory a handle holds drops by about
+  the size of its matrices, the result does not change, and a late msd_set_weight is refused with a clear message."""
+  import torch
+  spec = msd_amd.config.preset('small', num_steps=2)
+  params = msd_amd.synthetic.init_params(spec, 1)
+  batch = {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, 3)}
+  matrices = sum(v.size for k, v in params.items() if v.ndim == 2 and 'embedding' not in k and 'Embed_0' not in k) * 4
+  used, outs = {}, {}
+  for keep in (True, False):
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    model = msd_amd.InferenceModel(params, spec, keep_raw_weights=keep)
+    outs[keep], _ = model.predict(batch, seed=1)
+    torch.cuda.synchronize()
+    used[keep] = free0 - torch.cuda.mem_get_info()[0]
+    if not keep:
+      nm = model._get_native()
+      name = 'decoder/layers_0/mlp/wo/kernel'
+      with pytest.raises(RuntimeError, match='freed its staging copy'):
+        nm.set_weight(name, params[name])
+    del model
+  assert np.array_equal(np.asarray(outs[True]), np.asarray(outs[False]))
+  assert used[True] - used[False] > 0.8 * matrices, (used, matrices)

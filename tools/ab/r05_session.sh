@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-5 GPU sessions (gpurun -- 'bash tools/ab/r05_session.sh <what> <tag>').
+#   first   new GPU tests (key splits, layer-0 de-duplication, freed staging copies) + the launch-overlap micro-benchmark
+#           + in-process knob A/Bs (tools/ab/knob_ab.py) + the stripped library against round 4's shipped binary
+#   tests   full -m gpu suite
+#   final   tests + smoke + tools/profile_round.sh + default bench on the shipped binary
+WHAT=${1:-first}; TAG=${2:-r05a}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT
+B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1"
+one() {  # label, env assignments...
+  local label=$1; shift
+  env "$@" timeout 150 $B 2>$OUT/${TAG}_err.tmp | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$label]', d['value'], round(d['sample_ms_per_segment'],1))" || { echo "[$label] FAILED"; tail -5 $OUT/${TAG}_err.tmp; }
+}
+case $WHAT in
+first)
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "key_split or dedup or staging or single_decoder_pass or explicit_noise or batched_songs" > $OUT/${TAG}_new_tests.log 2>&1; tail -5 $OUT/${TAG}_new_tests.log
+  timeout 120 tools/ubench/launch_overlap_0 > $OUT/${TAG}_launch_overlap.log 2>&1; cat $OUT/${TAG}_launch_overlap.log
+  timeout 300 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_dedup_ab.json 'dedup_layer0=False' 'dedup_layer0=None' 2>&1 | grep -v Warning | tee $OUT/${TAG}_dedup_ab.log
+  timeout 600 python tools/ab/knob_ab.py --steps 500 --rounds 3 --json $OUT/${TAG}_split_sweep.json --tokens 128 --tokens 400 --tokens 700 --tokens 1000 --tokens 1300 --tokens 1536 \
+      'cross_key_split=4' 'cross_key_split=1' 'cross_key_split=2' 'cross_key_split=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_split_sweep.log
+  for r in 1 2; do
+    one "r04z (round 4's shipped binary)" MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r04z.so
+    one "new (library defaults)" X=0
+  done 2>&1 | tee $OUT/${TAG}_lib_ab.log
+  ;;
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
+  grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
+  ;;
+final)
+  timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile.log 2>&1; tail -4 $OUT/${TAG}_profile.log
+  timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 1500 $OUT/${TAG}_bench_default.json
+  ;;
+esac
