@@ -18,6 +18,10 @@ holds only the expected mel output and the seeds.
                              per-segment `rms_f32`): how far the reference's arithmetic itself drifts
                              along the chain.  Two processes: `chain64` and `chain32` (hours of CPU);
                              `chainpack` merges them.  Saved after every segment.
+  base_trained_n1000.npz, base_sharp2_n1000.npz   (round 5) the headline model with trained-like weights / with every
+                             decoder attention logit doubled: one 1000-step segment conditioned on a realistic context,
+                             float64 fixture + the float32 oracle's own rms (`robust_<kind>64`, `robust_<kind>32`,
+                             `robust_<kind>_pack`; ~10 CPU-minutes per run)
 """
 import os
 import sys
@@ -103,6 +107,46 @@ def trained_pack():
                       weight_seed=0, reshape_seed=1, noise_seed=0)
 
 
+def robust_params(spec, kind):
+  """Weights of the full-size robustness fixtures: `trained` = synthetic.trained_like (log-normal
+  channel gains, outlier channels, log-normal norm scales), `sharp2` = every decoder query kernel x2 (every attention
+  logit x2: max |s| ~ 13)."""
+  base = msd_amd.synthetic.init_params(spec, 0)
+  return msd_amd.synthetic.trained_like(base, seed=1) if kind == 'trained' else msd_amd.synthetic.sharp_attention(base, 2.0)
+
+
+def robust_batch(spec):
+  """One base_with_context segment WITH its context: segment 1 of the bench's song (tokens of segment 1), conditioned on
+  segment 0 of the committed float64 fixture base_with_context_n1000.npz (a realistic previous prediction)."""
+  c = spec.task_feature_lengths['targets_context']
+  prev = np.load(os.path.join(HERE, 'base_with_context_n1000.npz'))['mel'][:, :c].astype(np.float32)
+  return {'encoder_input_tokens': msd_amd.synthetic.segment_tokens(spec, 1), 'encoder_continuous_inputs': prev,
+          'encoder_continuous_mask': np.ones((1, c), np.int32)}
+
+
+def robust(kind, dtype, threads=None):
+  """base_with_context, ONE 1000-step segment, `kind` weights: float64 fixture / float32 yardstick (two processes)."""
+  spec = msd_amd.config.preset('base_with_context', num_steps=1000)
+  params = robust_params(spec, kind)
+  cfg, dc = helpers.oracle_configs(spec)
+  xp = backend.TorchBackend(dtype, threads=threads or os.cpu_count())
+  fm = fast.FastModel(xp, cfg, dc, params, True)
+  t, n = spec.task_feature_lengths['targets'], 128
+  init_z, noise = philox.segment_noise((1, t, n), 1000, seed=0, segment=1)
+  t0 = time.time()
+  out = xp.to_numpy(fm.predict(robust_batch(spec), init_z, noise)[0]).astype(np.float32)
+  print('robust %s %s: %.0fs' % (kind, dtype, time.time() - t0), flush=True)
+  np.save(os.path.join(HERE, '_robust_%s_%s.npy' % (kind, dtype)), out)
+
+
+def robust_pack(kind):
+  a = np.load(os.path.join(HERE, '_robust_%s_float64.npy' % kind))
+  b = np.load(os.path.join(HERE, '_robust_%s_float32.npy' % kind))
+  print('base_with_context, %s weights: float32 oracle vs float64 rms %.3e' % (kind, helpers.rms(b, a)))
+  np.savez_compressed(os.path.join(HERE, 'base_%s_n1000.npz' % kind), mel=a, rms_f32=helpers.rms(b, a), kind=kind,
+                      weight_seed=0, reshape_seed=1, noise_seed=0, segment=1)
+
+
 def chainpack():
   """Merge the float64 chain and the float32 oracle's own chain into one fixture."""
   a = np.load(os.path.join(HERE, '_chain64.npz'))
@@ -139,3 +183,9 @@ if __name__ == '__main__':
     trained_like('float32', nthr)
   if 'trainedpack' in what:
     trained_pack()
+  for kind in ('trained', 'sharp2'):   # e.g. robust_trained64 robust_trained32 robust_trained_pack
+    for dt, tag in (('float64', '64'), ('float32', '32')):
+      if 'robust_%s%s' % (kind, tag) in what:
+        robust(kind, dt, nthr)
+    if 'robust_%s_pack' % kind in what:
+      robust_pack(kind)

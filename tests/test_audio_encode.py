@@ -59,3 +59,57 @@ def test_encode_shapes_silence_and_tone():
   # features scale into the network range like any context spectrogram (audio_codecs.py:166-174)
   scaled = codec.scale_features(mel, clip=True)
   assert scaled.min() >= -1.0 and scaled.max() <= 1.0
+
+
+def test_stft_magnitude_against_scipy_and_torch():
+  """External pins for N4: the framing + window + FFT of `stft_magnitude` against two STFTs this
+  package did not write.
+    scipy.signal.stft(window='hann' (periodic: get_window's default), nperseg=640, noverlap=320, nfft=1024,
+      boundary=None, padded=False) frames the signal exactly like tf.signal.stft (frame k = samples [320 k, 320 k + 640),
+      zero-padded to 1024 BEHIND the window) and divides by the window's sum;
+    torch.stft(n_fft=1024, hop_length=320, win_length=640, center=False) centres the 640-sample window inside its
+      1024-sample frame, i.e. it sees the samples tf.signal sees when the signal is shifted right by 192 -- a shift of
+      the windowed frame inside the FFT buffer changes phases, not magnitudes.
+  The zero extension of pad_end=True (ceil(n / 320) frames) is applied to the inputs of both."""
+  import scipy.signal
+  import torch
+  rng = np.random.default_rng(3)
+  for n in (3200, 3333, 641):                                 # whole frames, a ragged end, barely two frames
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    mag = ac.stft_magnitude(x, 640, 320, 1024)
+    n_frames = -(-n // 320)
+    assert mag.shape == (2, n_frames, 513)
+    padded = np.zeros((2, (n_frames - 1) * 320 + 640), np.float32)
+    padded[:, :n] = x
+    _, _, z = scipy.signal.stft(padded, fs=16000, window='hann', nperseg=640, noverlap=320, nfft=1024, boundary=None,
+                                padded=False, return_onesided=True)
+    win_sum = scipy.signal.get_window('hann', 640).sum()
+    want = np.abs(z).transpose(0, 2, 1) * win_sum              # [batch, frames, bins]
+    assert want.shape == mag.shape
+    np.testing.assert_allclose(mag, want, rtol=2e-4, atol=2e-3)
+    shifted = np.zeros((2, (n_frames - 1) * 320 + 1024), np.float32)
+    shifted[:, 192:192 + padded.shape[1]] = padded
+    zt = torch.stft(torch.as_tensor(shifted), n_fft=1024, hop_length=320, win_length=640,
+                    window=torch.hann_window(640, periodic=True), center=False, return_complex=True)
+    want_t = zt.abs().numpy().transpose(0, 2, 1)
+    assert want_t.shape == mag.shape
+    np.testing.assert_allclose(mag, want_t, rtol=2e-4, atol=2e-3)
+  np.testing.assert_allclose(ac.hann_window_periodic(640), scipy.signal.get_window('hann', 640), atol=1e-7)
+  np.testing.assert_allclose(ac.hann_window_periodic(640), torch.hann_window(640, periodic=True).numpy(), atol=1e-6)
+
+
+def test_mel_matrix_against_a_second_construction():
+  """The HTK filter bank built a second way (no library offers tf.signal's variant: torchaudio / librosa -- absent here
+  anyway -- draw their triangles linear in HERTZ between mel-spaced points, tf.signal linear in MEL): numpy.interp of
+  the three-point function (lower, 0), (centre, 1), (upper, 0) over the bins' mel values, band edges from the inverse
+  formula f = 700 (e^{m / 1127} - 1) instead of a mel-domain linspace of the end points.  HTK's own anchor: 1000 Hz is
+  1000 mel (999.99)."""
+  m = ac.linear_to_mel_weight_matrix(128, 513, 16000, 0.0, 8000.0)
+  assert abs(1127.0 * math.log(1.0 + 1000.0 / 700.0) - 1000.0) < 0.02
+  top = 1127.0 * math.log(1.0 + 8000.0 / 700.0)
+  edges_hz = 700.0 * (np.exp(np.arange(130) * (top / 129.0) / 1127.0) - 1.0)
+  edges_mel = 1127.0 * np.log1p(edges_hz / 700.0)
+  bins_mel = 1127.0 * np.log1p(np.arange(513) * (8000.0 / 512.0) / 700.0)
+  second = np.stack([np.interp(bins_mel, edges_mel[j:j + 3], [0.0, 1.0, 0.0], left=0.0, right=0.0) for j in range(128)], 1)
+  second[0] = 0.0                                             # tf.signal drops the DC bin
+  np.testing.assert_allclose(m, second, atol=2e-6)

@@ -141,3 +141,70 @@ def test_zarr_round_trip_property(tmp_path):
     checkpoints.write_zarr_array(d, arr, compressor=comp, chunks=chunks if shape else None)
     np.testing.assert_array_equal(checkpoints.read_zarr_array(d), arr)
   check()
+
+
+def test_t5x_directory_built_with_msgpack_and_raw_zarr_not_with_our_writer(tmp_path):
+  """The reader against a checkpoint directory this package's WRITER never touched: the index is
+  packed with the `msgpack` library exactly as flax.serialization / t5x.checkpoints do it --
+    * {'version': 3, 'optimizer': {'state': {'step': ..., 'param_states': {...}}, 'target': {...}}}
+    * a small array inline as flax's ExtType 1 = packb((shape, dtype.name, bytes)), the step as an int32 0-d array
+    * a large array as the TensorStore spec t5x stores in its place ({'driver': 'zarr', 'kvstore': {'driver': 'file',
+      'path': 'target.<dotted name>'}, 'metadata': {...}, 'dtype': ...}), with the optimizer's slots of the same
+      parameters stored the same way under 'state.param_states.*' (they must be skipped)
+  -- and the arrays are raw zarr v2 directories laid out by hand the way t5x writes them: several chunks ([chunk, full]
+  row blocks), gzip-compressed C-order bytes of FULL chunks (ragged last block padded), '.zarray' JSON per the zarr
+  v2 spec.  Names, shapes, values and the step must come out."""
+  import msgpack
+  rng = np.random.default_rng(5)
+  ckpt = tmp_path / 'model' / 'checkpoint_5000'
+  ckpt.mkdir(parents=True)
+
+  def zarr_dir(rel, arr, rows_per_chunk):
+    d = ckpt / rel
+    d.mkdir()
+    chunks = [rows_per_chunk] + list(arr.shape[1:])
+    (d / '.zarray').write_text(json.dumps({
+        'chunks': chunks, 'compressor': {'id': 'gzip', 'level': 1}, 'dtype': arr.dtype.str, 'fill_value': None,
+        'filters': None, 'order': 'C', 'shape': list(arr.shape), 'zarr_format': 2}))
+    for i in range(-(-arr.shape[0] // rows_per_chunk)):
+      block = np.zeros(chunks, arr.dtype)
+      part = arr[i * rows_per_chunk:(i + 1) * rows_per_chunk]
+      block[:len(part)] = part
+      key = '.'.join([str(i)] + ['0'] * (arr.ndim - 1))
+      (d / key).write_bytes(gzip.compress(block.tobytes(), 1))
+    return {'driver': 'zarr', 'dtype': arr.dtype.name, 'kvstore': {'driver': 'file', 'path': rel},
+            'metadata': {'chunks': chunks, 'compressor': {'id': 'gzip'}, 'shape': list(arr.shape)}}
+
+  def inline(arr):
+    arr = np.asarray(arr)
+    return msgpack.ExtType(1, msgpack.packb((list(arr.shape), arr.dtype.name, arr.tobytes()), use_bin_type=True))
+
+  kernel = rng.standard_normal((70, 48)).astype(np.float32)           # 3 row chunks of 32, ragged last
+  embed = rng.standard_normal((20, 16)).astype(np.float32)
+  scale = rng.standard_normal((48,)).astype(np.float32)
+  state = {
+      'version': 3,
+      'optimizer': {
+          'state': {'step': inline(np.asarray(5000, np.int32)),
+                    'param_states': {'decoder': {'layers_0': {'mlp': {'wo': {'kernel': {
+                        'v_row': zarr_dir('state.param_states.decoder.layers_0.mlp.wo.kernel.v_row', np.ones((70,), np.float32), 64)}}}}}}},
+          'target': {
+              'decoder': {'layers_0': {'mlp': {'wo': {'kernel': zarr_dir('target.decoder.layers_0.mlp.wo.kernel', kernel, 32)}},
+                                       'pre_mlp_layer_norm': {'scale': inline(scale)}}},
+              'token_encoder': {'token_embedder': {'embedding': zarr_dir('target.token_encoder.token_embedder.embedding', embed, 8)}},
+          },
+      },
+  }
+  (ckpt / 'checkpoint').write_bytes(msgpack.packb(state, use_bin_type=True))
+  for path in (str(ckpt), str(tmp_path / 'model')):
+    got = checkpoints.load_t5x_checkpoint(path)
+    assert int(got.pop('__step__')) == 5000
+    assert set(got) == {'decoder/layers_0/mlp/wo/kernel', 'decoder/layers_0/pre_mlp_layer_norm/scale',
+                        'token_encoder/token_embedder/embedding'}
+    np.testing.assert_array_equal(got['decoder/layers_0/mlp/wo/kernel'], kernel)
+    np.testing.assert_array_equal(got['decoder/layers_0/pre_mlp_layer_norm/scale'], scale)
+    np.testing.assert_array_equal(got['token_encoder/token_embedder/embedding'], embed)
+    assert all(v.dtype == np.float32 for v in got.values())
+  # a renamed directory still reports the step saved INSIDE the index (the reference reads train_state.step)
+  os.rename(str(ckpt), str(tmp_path / 'model' / 'copy_of_it'))
+  assert int(checkpoints.load_t5x_checkpoint(str(tmp_path / 'model' / 'copy_of_it'))['__step__']) == 5000
