@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights appended to msd_config.
+#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
                                    4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
                                       NO environment variable.  3: MSD_ERR_RANGE; distinct bfloat16-plane precisions */
@@ -163,7 +163,10 @@ typedef struct msd_config {
                                      count and the batch, else 1, 2, 4 or 8 */
   int32_t keep_raw_weights;       /* 0 = msd_finalize_weights frees the float32 staging copy of every matrix it has
                                      packed into operand planes (1.5 GB of 1.65 at base_with_context); 1 = keep them
-                                     (msd_set_weight + msd_finalize_weights can then be repeated on this handle) */
+                                     (they have no reader; for memory-accounting A/Bs) */
+  int32_t kv_touch_ahead;         /* the cross-attention launches' prefetch wave touches the cached K / V^T lines this
+                                     many 128-key ring stages ahead of their LDS-DMA (they are HBM-cold at every
+                                     step): 0 = the library's choice, -1 = off, 1 .. 16 */
 } msd_config;
 
 const char* msd_version(void);

@@ -57,6 +57,8 @@ struct AttnParams {
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
   unsigned sat_tag = 1;
   int qp = 0;                // query-side single-plane switches (attention_kernel QP bits 0 / 1), NP = 2 only
+  int touch_ahead = 0;       // > 0 (launches with a prefetch wave only): that wave also touches the K / V^T lines of the
+                             // block's ring stages this many stages AHEAD of their LDS-DMA (kv_touch_ahead below)
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -74,12 +76,16 @@ constexpr int kAttWStride = 32 * kAttOLD + 64;         // per-wave merge slab (f
 
 constexpr int kAttQBytes = 32 * 128;                   // Q tile of one query block and plane: [32 rows][64 d], behind the ring
 
+// ring + Q tiles (reused as the merge slab), then 256 bytes nobody reads: where the touch-ahead's LDS-DMA lands
+constexpr int kAttTouchSink = 256;
 template <int NP, int NS, int QB>
-constexpr int attention_smem() {
+constexpr int attention_work_smem() {
   return (NS * NP * (kAttKBytes + kAttVBytes) + QB * NP * kAttQBytes > QB * kAttKG * kAttWStride * 4)
              ? NS * NP * (kAttKBytes + kAttVBytes) + QB * NP * kAttQBytes
              : QB * kAttKG * kAttWStride * 4;
 }
+template <int NP, int NS, int QB>
+constexpr int attention_smem() { return attention_work_smem<NP, NS, QB>() + kAttTouchSink; }
 
 // QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
 // QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
@@ -87,13 +93,87 @@ constexpr int attention_smem() {
 // QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
 // O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
 // (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
+// K / V^T touch-ahead (round 5), run by the block's PREFETCH WAVE.  The cached cross-attention K / V^T are HBM-cold at every
+// step and the ring holds NS = 2 stages of 64 KiB: a block waits one full HBM latency (3.5 us: the
+// "issued -> stage 0 landed" of the phase stamps) for its first stage and AGAIN for every stage it issues later -- its
+// key loop runs at 2.5 us per stage where the MFMAs need 0.65 (profiles/r04z_phase_times*.txt; at 8 songs per handle a
+// block walks 11 stages: 62 of a layer's 320 us).  More ring does not fit the LDS; the L2 does hold a few stages per
+// block.  So the prefetch wave -- whose vmcnt nobody waits for -- touches one dword per 128-byte line of the stages
+// `ahead` (> 0) stages in front of the LDS-DMA front: stages NS .. NS + ahead - 1 at entry, then one more stage per key-loop
+// barrier, which it takes part in (an alive wave counts at s_barrier: it executes exactly the compute waves' barriers --
+// one per stage of this block + the two of the merge -- and ends).  The DMA of such a stage then finds its lines in the
+// XCD's L2 / the memory-side cache.  Same bytes from HBM, earlier; results are untouched (nobody reads a touch).
+// A touch is ONE DWORD PER LANE BY LDS-DMA into 256 bytes of LDS nobody reads (`sink_lds`, behind the block's working
+// set): no destination register, so none of the register hazards of the weight touches (gemm_h16.h prefetch_wave: a
+// touch into a VGPR inside this run-time loop had its register reused by the compiler -- check_prefetch_regs.py caught
+// it on the listing).
+template <int NP, int NS, int PF>
+__device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_lds) {
+  const int lane = (int)threadIdx.x & 63;
+  const int kl2 = p.ksplit_log2;
+  const int ks = (int)(blockIdx.y & (p.ksplit - 1)), head = blockIdx.x, seg = blockIdx.z;
+  int nkeys;
+  {
+    const int* nkp = p.n_keys + seg;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nkeys) : "s"(nkp) : "memory");
+  }
+  const int nst_all = (nkeys + kAttStageKeys - 1) / kAttStageKeys;
+  const int nst = nst_all > ks ? (nst_all - ks + p.ksplit - 1) >> kl2 : 0;   // (the compute waves' count, to the letter)
+  const int ahead = p.touch_ahead;
+  const int last_row = p.k_rows - 1, last_kcol = (p.vt_cols > 0 ? p.vt_cols : p.vt_ld) - 8;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // one stage = per plane 128 K rows of 128 bytes + 64 V^T rows of 256 bytes = 256 lines: 4 wave-wide touches per plane
+  auto touch_stage = [&](int st) {
+    const int kb = (ks + st * p.ksplit) * kAttStageKeys;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = u * 64 + lane;
+        const h16_t* src;
+        if (u < 2) {           // K rows kb + tt
+          int row = kb + tt;
+          row = row < last_row ? row : last_row;
+          src = p.k[pl] + (size_t)seg * p.k_seg_stride + (size_t)row * p.ldk + head * 64;
+        } else {               // V^T rows d = (tt - 128) / 2, half = tt & 1 (64 keys = 128 bytes each)
+          const int d = (tt - 128) >> 1;
+          int col = kb + (tt & 1) * 64;
+          col = col < last_kcol ? col : last_kcol;
+          src = p.vt[pl] + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64 + d) * p.vt_ld + col;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)sink_lds, 4, 0, 0);
+      }
+    }
+  };
+  for (int st = NS; st < NS + ahead && st < nst; ++st) touch_stage(st);
+  {   // the launch's weight target (a later GEMM's planes), as before
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    prefetch_wave<PF, true>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], sink_lds);
+  }
+  {
+    for (int st = 0; st < nst; ++st) {
+      __builtin_amdgcn_s_barrier();                 // the compute waves' barrier of stage st
+      if (st + NS + ahead < nst) touch_stage(st + NS + ahead);
+    }
+    __builtin_amdgcn_s_barrier();                   // ... and the two of their partial merge
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA of this wave outlives it (the LDS goes back with the block)
+  }
+}
+
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
   warm_kernargs<kernarg_lines<AttnParams>()>();
   if constexpr (kPfWaveAttn && PF != kPfNone) {
-    if (threadIdx.x >= QB * kAttKG * 64) {   // the prefetch wave
-      const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-      prefetch_wave<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0]);
+    if (threadIdx.x >= QB * kAttKG * 64) {   // the prefetch wave: a later GEMM's weights (+ this block's later K / V^T stages)
+      if (p.touch_ahead <= 0) {   // weights only, and the wave ends (an ended wave does not count at s_barrier)
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        prefetch_wave<PF>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0]);
+        return;
+      }
+      extern __shared__ __attribute__((aligned(16))) char smem_pf[];
+      kv_touch_ahead<NP, NS, PF>(p, smem_pf + attention_work_smem<NP, NS, QB>());
       return;
     }
   }

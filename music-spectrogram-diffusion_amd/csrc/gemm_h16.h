@@ -127,8 +127,12 @@ __device__ __forceinline__ void prefetch_done(const PrefetchRegsT<PF>& keep) {
 // (-1.0 % step time same-box against the in-epilogue touches, profiles/r03f_env_ab.log)
 constexpr bool kPfWave = true;       // GEMM launches
 constexpr bool kPfWaveAttn = true;   // attention launches
-template <int PF>
-__device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk, int nblk, const void* valid) {
+// LDS_SINK: the touches are LDS-DMA dwords into 256 bytes of LDS nobody reads instead of loads into a
+// register -- for a prefetch wave that goes on living behind them (attention.h kv_touch_ahead): there the register form's
+// hazard (the compiler reusing the destination once it believes the value dead) cannot be excluded by construction.
+template <int PF, bool LDS_SINK = false>
+__device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk, int nblk, const void* valid,
+                                              char* sink_lds = nullptr) {
   if constexpr (PF != kPfNone) {
     constexpr int TOUCHES = 4 * kPrefetchPerThread;
     const int lane = (int)threadIdx.x & 63;
@@ -153,7 +157,13 @@ __device__ __forceinline__ void prefetch_wave(const WeightPrefetch& pf, int blk,
         const char* row_ptr = t.base[pl] + (size_t)row0 * t.row_stride;
         const bool in = rp0 < rows * planes && row0 + sub < rows && line < lpr;
         const char* src = in ? row_ptr + lane_off : reinterpret_cast<const char*>(valid);
-        asm volatile("global_load_dword %0, %1, off ; msd_prefetch" : "+v"(sink) : "v"(src) : "memory");
+        if constexpr (LDS_SINK) {
+          typedef const __attribute__((address_space(1))) void* pf_gptr_t;
+          typedef __attribute__((address_space(3))) void* pf_lptr_t;
+          __builtin_amdgcn_global_load_lds((pf_gptr_t)src, (pf_lptr_t)(size_t)(unsigned)(size_t)sink_lds, 4, 0, 0);
+        } else {
+          asm volatile("global_load_dword %0, %1, off ; msd_prefetch" : "+v"(sink) : "v"(src) : "memory");
+        }
       }
     }
     asm volatile("" ::"v"(sink));

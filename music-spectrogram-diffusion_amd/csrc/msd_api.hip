@@ -158,6 +158,7 @@ struct msd_model {
   int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
+  int kv_touch_ahead = 4;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
   // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
@@ -547,6 +548,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
   p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
+  p.touch_ahead = kc == KC_ATTN_CROSS ? c.m->kv_touch_ahead : 0;   // (the decoder's cached K / V^T: HBM-cold at every step)
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -938,9 +940,13 @@ inline int cross_split(const msd_model* m, int batch, int e) {
   } else {
     const int blocks = m->H * (m->T / 64) * batch;
     want = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
-    // the key split pays only on a long key axis (the 256-frame context region runs unsplit)
+    // the key split pays only on a long key axis (the 256-frame context region runs unsplit) ...
     const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1);
     want = std::min(want, cap);
+    // ... and only as far as THIS segment's keys go: measured per key count at one song (profiles/r05a_split_sweep.log,
+    // ms per 500 steps, split 1 / 2 / 4 / 8): 385 keys 482 / 481 / 488 / 524 . 657: 505 / 491 / 495 / 525 . 957: 527 / 502 /
+    // 496 / 526 . 1257: 549 / 516 / 507 / 534 . 1793: 603 / 545 / 518 / 543 -- two blocks up to ~6 stages, four beyond
+    if (want > 2 && cross_keys_max(m, batch, e) <= 6 * kAttStageKeys) want = 2;
   }
   want = std::min(want, std::min(m->cross_ksplit, stages));
   int ks = 1;
@@ -1199,6 +1205,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->cross_key_split != 0 && cfg->cross_key_split != 1 && cfg->cross_key_split != 2 && cfg->cross_key_split != 4 &&
       cfg->cross_key_split != 8) return bad("cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8");
   if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
+  if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1213,6 +1220,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->graph_steps > 0) m->graph_steps = cfg->graph_steps;
   if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
   m->dedup_layer0 = cfg->dedup_layer0 != 2;
+  if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-
@@ -1624,6 +1632,12 @@ int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t ma
   else if (b == "x") { f32 = m->x; count = Mmax * m->D; }
   else if (b == "eps") { f32 = m->eps; count = Mmax * m->ND; }
   else if (b == "z") { f32 = m->z; count = (int64_t)m->Bmax * m->T * m->ND; }
+  else if (b == "ssq") { f32 = m->ssq; count = Mmax * (m->D / kNarrowTile); }
+  else if (b == "y") { pl = &m->y; count = Mmax * m->D; }
+  else if (b == "qk") { pl = &m->qk; count = Mmax * 2 * m->J; }
+  else if (b == "vt") { pl = &m->vt; count = Mmax * m->J; }
+  else if (b == "ao") { pl = &m->ao; count = Mmax * m->J; }
+  else if (b == "g") { pl = &m->g; count = Mmax * m->F; }
   else if (b == "enc") { pl = &m->enc; count = (int64_t)m->S_pad * m->D; }
   else if (b == "cross_k") { pl = &m->kc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }
   else if (b == "cross_vt") { pl = &m->vtc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }

@@ -23,6 +23,13 @@ first)
     one "new (library defaults)" X=0
   done 2>&1 | tee $OUT/${TAG}_lib_ab.log
   ;;
+second)  # layer-0 de-duplication diagnostic; K / V touch-ahead: parity tests, then in-process A/B at one song and at 8 songs
+  timeout 120 python tools/diag/dedup_diff.py tiny_context 1 2>&1 | grep -v Warning | tee $OUT/${TAG}_dedup_diff.log
+  timeout 120 python tools/diag/dedup_diff.py base_with_context 1 2>&1 | grep -v Warning | tee -a $OUT/${TAG}_dedup_diff.log
+  timeout 600 python -m pytest tests/test_gpu_model.py tests/test_golden.py -m gpu -q -x -k "key_split or base_size or base_with_context_1000 or batched_songs or sum_cross" > $OUT/${TAG}_touch_tests.log 2>&1; tail -5 $OUT/${TAG}_touch_tests.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 4 --json $OUT/${TAG}_touch_ab.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 'kv_touch_ahead=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_ab.log
+  timeout 400 python tools/ab/knob_ab.py --batch 8 --steps 200 --rounds 3 --json $OUT/${TAG}_touch_ab_b8.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 'kv_touch_ahead=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_ab_b8.log
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
