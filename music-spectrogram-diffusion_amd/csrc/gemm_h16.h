@@ -873,6 +873,18 @@ struct EpiResidual {
   }
 };
 
+// w = v (.) g as ROUNDED float32 products.  The planes written from w are hi = r16(w), lo = r16(w - hi): left to the
+// compiler, the product is contracted into that subtraction as an FMA in some instantiations of an epilogue and not in
+// others -- the first version of the duplicating epilogue below wrote y planes one ulp off the one-pass form's (found
+// with tools/diag/dedup_diff.py on a debug build with stop points, profiles/r05c_dedup_diff.log).  Under
+// `fp contract(off)` these multiplications carry no contract flag and cannot be fused (HIP's __fmul_rn is a plain
+// `x * y` and would be), so every form of the residual epilogue writes the same bits.
+__device__ __forceinline__ void gain8(const float (&v)[8], float4 g0, float4 g1, float (&w)[8]) {
+#pragma clang fp contract(off)
+  w[0] = v[0] * g0.x; w[1] = v[1] * g0.y; w[2] = v[2] * g0.z; w[3] = v[3] * g0.w;
+  w[4] = v[4] * g1.x; w[5] = v[5] * g1.y; w[6] = v[6] * g1.z; w[7] = v[7] * g1.w;
+}
+
 // Residual add that also PRODUCES the folded-norm inputs of the next projection:
 //   x += acc ;  ssq[m][col/32] = sum over each 32-column group of x^2 ;
 //   y = x (.) g  as bf16 planes, g = g_lo for rows < split_row, g_hi otherwise
@@ -954,9 +966,9 @@ struct EpiResidualNorm {
     const bool lo_rows = row < split_row;
     if (act && (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr))) {
       const f32x4 g0 = lo_rows ? gl[n / 4] : gh[n / 4], g1 = lo_rows ? gl[n / 4 + 1] : gh[n / 4 + 1];
-      v[0] *= g0[0]; v[1] *= g0[1]; v[2] *= g0[2]; v[3] *= g0[3];
-      v[4] *= g1[0]; v[5] *= g1[1]; v[6] *= g1[2]; v[7] *= g1[3];
-      store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
+      float w[8];
+      gain8(v, make_float4(g0[0], g0[1], g0[2], g0[3]), make_float4(g1[0], g1[1], g1[2], g1[3]), w);
+      store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
     }
     rc.commit(sf.p, sf.tag);
   }
@@ -998,8 +1010,10 @@ struct EpiResidualNorm {
         float4 g0, g1, h0, h1;
         LG(true, n, col, g0, g1);
         LG(false, n, col, h0, h1);
-        const float w[8] = {v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w, v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w};
-        const float u[8] = {v[0] * h0.x, v[1] * h0.y, v[2] * h0.z, v[3] * h0.w, v[4] * h1.x, v[5] * h1.y, v[6] * h1.z, v[7] * h1.w};
+        // (gain8: both copies must carry the bits the one-pass form computes)
+        float w[8], u[8];
+        gain8(v, g0, g1, w);
+        gain8(v, h0, h1, u);
         store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
         store_h16x8<NP>(y, row2 * ldx + col, u, rc);
       } else {
@@ -1007,9 +1021,9 @@ struct EpiResidualNorm {
         if (lo_rows ? (g_lo != nullptr) : (g_hi != nullptr)) {
           float4 g0, g1;
           LG(lo_rows, n, col, g0, g1);
-          v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
-          v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
-          store_h16x8<NP>(y, (size_t)row * ldx + col, v, rc);
+          float w[8];
+          gain8(v, g0, g1, w);
+          store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
         }
       }
     };

@@ -158,7 +158,7 @@ struct msd_model {
   int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
-  int kv_touch_ahead = 4;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
+  int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
   // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
@@ -417,7 +417,12 @@ TileShape pick_tile(int M, int N, int align, bool wide48 = false, int K = 0) {
     }
     return {64, 64};
   }
-  if (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE) && big && N % 96 == 0) return {128, 96};   // N = D projections of a decoder layer
+  if (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE) && big && N % 96 == 0) {   // N = D projections of a decoder layer
+    // ... on 64 x 96 where 128 x 96 would leave CUs without a tile: the cross-attention's query / output projections run
+    // on the conditional rows only -- M = 2048 at 8 songs is 128 tiles of 128 x 96 on 256 CUs (round 5)
+    if (M % 64 == 0 && tile_cost(M, N, 64, 96) < tile_cost(M, N, 128, 96)) return {64, 96};
+    return {128, 96};
+  }
   // 32 x 48 (round 4; residual + folded-norm epilogue only): 512 x 768 outputs are 256 such tiles -- one per CU with
   // 80 operand rows per K-tile, where 32 x 32 is 384 blocks (two on half the CUs: 128 rows) and 64 x 32 is 192 (96
   // rows on three quarters of the chip)
@@ -458,6 +463,7 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
   } else {
     if constexpr (NP == 2 && (TK == TK_TALL || TK == TK_SQUARE)) {
       if (t.bm == 128) MSD_GO_BIG(128, 96)
+      if (t.bm == 64 && t.bn == 96) MSD_GO(64, 96, 3);
     }
     if constexpr (TK == TK_TALL) {
       if (t.bm == 64) MSD_GO(64, kNarrowTile, kTallNS);
@@ -495,7 +501,8 @@ hipError_t prepare_gemms() {
     PREP(64, 96, 3, EpiQKV<NP>) PREP(64, 128, 3, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiQKV<NP>) PREP(128, 128, 2, EpiGeglu<NP>)
     PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreH16<NP>)
-    { using EpiDup = EpiResidualNorm<NP, true>; PREP(128, 96, 2, EpiDup) }
+    PREP(64, 96, 3, EpiResidual) PREP(64, 96, 3, EpiResidualNorm<NP>) PREP(64, 96, 3, EpiStoreH16<NP>)
+    { using EpiDup = EpiResidualNorm<NP, true>; PREP(128, 96, 2, EpiDup) PREP(64, 96, 3, EpiDup) }
     PREP(32, kWide48, 4, EpiResidualNorm<NP>)
   }
   PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreH16<NP>)
@@ -548,7 +555,12 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
   p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
-  p.touch_ahead = kc == KC_ATTN_CROSS ? c.m->kv_touch_ahead : 0;   // (the decoder's cached K / V^T: HBM-cold at every step)
+  // K / V^T touch-ahead: the decoder's cross-attention (its cache is HBM-cold at every step) at ONE song per handle,
+  // where the launch is latency-bound.  Same-process A/B, ms per segment, touches off -> 2 stages ahead
+  // (profiles/r05b_touch_ab*.log, r05c_touch_b{2,4}.log): one song 943.1 -> 930.1 (-1.4 %; 4 / 8 ahead: 932.8 / 931.0);
+  // 2 songs +1.1 %, 4 songs +3.5 %, 8 songs +3.1 % -- batched launches are bandwidth-bound and the touches only add
+  // requests -- so the library turns it on for one song only, whatever msd_config.kv_touch_ahead asks for beyond that.
+  p.touch_ahead = (kc == KC_ATTN_CROSS && segs == 1) ? c.m->kv_touch_ahead : 0;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -939,7 +951,11 @@ inline int cross_split(const msd_model* m, int batch, int e) {
     want = m->cfg.cross_key_split;
   } else {
     const int blocks = m->H * (m->T / 64) * batch;
-    want = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1
+    want = blocks > 0 ? (192 + blocks - 1) / blocks : 1;   // 1 song: 4, 2-3 songs: 2, from 4 songs: 1 ...
+    // ... but 2 on a long key axis: 12 x 4 x songs blocks of ~10 ring stages each are 1.5 rounds over the 256 CUs at 8
+    // songs; halves of them pack better than the merge launch costs (ms per 300 / 200 steps, split 1 -> 2: 4 songs 759.7 ->
+    // 752.4, 8 songs 782.4 -> 777.5; split 4 at 8 songs: 806.3; profiles/r05c_split_b8.log, r05c_touch_b4.log)
+    if (want < 2 && cross_keys_max(m, batch, e) > 6 * kAttStageKeys) want = 2;
     // the key split pays only on a long key axis (the 256-frame context region runs unsplit) ...
     const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1);
     want = std::min(want, cap);

@@ -30,6 +30,30 @@ second)  # layer-0 de-duplication diagnostic; K / V touch-ahead: parity tests, t
   timeout 400 python tools/ab/knob_ab.py --rounds 4 --json $OUT/${TAG}_touch_ab.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 'kv_touch_ahead=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_ab.log
   timeout 400 python tools/ab/knob_ab.py --batch 8 --steps 200 --rounds 3 --json $OUT/${TAG}_touch_ab_b8.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 'kv_touch_ahead=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_ab_b8.log
   ;;
+third)   # where the de-duplicated step parts ways (debug build with stop points); key split and touch-ahead by batch size
+  for stop in 2 1; do
+    echo "== stop point $stop (2: after layer 0's self-attention, 1: after its attention-out)"
+    MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_dbg.so MSD_DBG_STOP=$stop timeout 120 python tools/diag/dedup_diff.py tiny_context 1 2>&1 | grep -v Warning
+  done | tee $OUT/${TAG}_dedup_diff.log
+  timeout 400 python tools/ab/knob_ab.py --batch 8 --steps 200 --rounds 3 --json $OUT/${TAG}_split_b8.json 'kv_touch_ahead=0,cross_key_split=1' 'kv_touch_ahead=0,cross_key_split=2' 'kv_touch_ahead=0,cross_key_split=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_split_b8.log
+  timeout 400 python tools/ab/knob_ab.py --batch 2 --steps 300 --rounds 3 --json $OUT/${TAG}_touch_b2.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=0,cross_key_split=4' 'kv_touch_ahead=2,cross_key_split=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_b2.log
+  timeout 400 python tools/ab/knob_ab.py --batch 4 --steps 300 --rounds 3 --json $OUT/${TAG}_touch_b4.json 'kv_touch_ahead=0' 'kv_touch_ahead=2' 'kv_touch_ahead=0,cross_key_split=2' 'kv_touch_ahead=2,cross_key_split=2' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_b4.log
+  ;;
+fourth)  # bitwise tests of the de-duplication after the contraction fix; batched path with the new tile rule / key split;
+         # then the whole -m gpu suite on this binary
+  timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "dedup or staging or batched_songs or base_size" > $OUT/${TAG}_dedup_tests.log 2>&1; tail -4 $OUT/${TAG}_dedup_tests.log
+  for r in 1 2; do
+    for L in "MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r04z.so" "X=0"; do
+      env $L timeout 200 python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[batch 8 $L]', d['value'], d['ms_per_step'])"
+    done
+  done 2>&1 | tee $OUT/${TAG}_batch_ab.log
+  for r in 1 2; do
+    one "r04z" MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r04z.so
+    one "new" X=0
+  done 2>&1 | tee $OUT/${TAG}_lib_ab.log
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
+  grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
