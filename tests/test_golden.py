@@ -218,3 +218,34 @@ def test_small_sharp_attention_1000_steps(gain):
   # (measured at gain 4: P one plane x1.10 of the floor, Q and P one plane 4.5e-4)
   assert errs['P one plane'] <= 1.3 * floor and errs['P one plane'] <= 1e-3
   assert errs['Q and P one plane'] <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['trained', 'sharp2'])
+def test_base_with_context_robustness_1000_steps(kind):
+  """The HEADLINE model off its fresh-initialiser comfort zone (the real checkpoints are trained,
+  gin/models/diffusion/context/t5_base.gin:70-83): base_with_context, one 1000-step segment conditioned on a realistic
+  previous prediction, with `trained` = synthetic.trained_like weights (log-normal channel gains, x6 outlier channels,
+  log-normal norm scales) and with `sharp2` = every decoder attention logit doubled.  Fixture: float64 oracle + the
+  float32 oracle's own rms (tests/golden/make_golden.py robust_*).  Default mode (f16x3, all planes): north_star's
+  1e-3, float32-class (<= 1.3 x the float32 oracle's own error), and the half-plane range holds -- the model is built
+  with range_fallback=False, so an activation beyond 65504 would fail the test instead of silently switching planes."""
+  import sys
+  from oracle import philox
+  path = os.path.join(GOLD, 'base_%s_n1000.npz' % kind)
+  if not os.path.exists(path):
+    pytest.skip('fixture not generated: python tests/golden/make_golden.py robust_%s64 robust_%s32 robust_%s_pack' % (kind, kind, kind))
+  sys.path.insert(0, GOLD)
+  import make_golden
+  g = np.load(path)
+  spec = msd_amd.config.preset('base_with_context', num_steps=1000)
+  params = make_golden.robust_params(spec, kind)
+  batch = make_golden.robust_batch(spec)
+  t = spec.task_feature_lengths['targets']
+  init_z, noise = philox.segment_noise((1, t, 128), 1000, seed=int(g['noise_seed']), segment=int(g['segment']))
+  model = msd_amd.InferenceModel(params, spec, range_fallback=False)
+  got, _ = model.predict(batch, init_z=init_z, noise=noise)
+  assert model.precision == 'f16x3'
+  err, floor = helpers.rms(got, g['mel']), float(g['rms_f32'])
+  print('base_with_context, %s weights, 1000 steps: device %.3e | float32 oracle %.3e | x%.2f' % (kind, err, floor, err / floor))
+  assert err <= 1e-3 and err <= 1.3 * floor

@@ -54,6 +54,16 @@ fourth)  # bitwise tests of the de-duplication after the contraction fix; batche
   timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
   ;;
+fifth)   # fused projection + sampler: bitwise tests in every sampler mode; the new library with every round-5 shortcut OFF
+         # against round 4's shipped binary (what did the source clean-up cost?), then with the defaults
+  timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_fused_ops.py -m gpu -q -x -k "exact_launch or fused_projection or staging or sampler" > $OUT/${TAG}_fuse_tests.log 2>&1; tail -4 $OUT/${TAG}_fuse_tests.log
+  OFF='dedup_layer0=False,fuse_final_sampler=False,kv_touch_ahead=0,cross_key_split=4'
+  for r in 1 2; do
+    MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r04z.so timeout 200 python tools/ab/knob_ab.py --rounds 4 'graph_steps=8' 2>&1 | grep -E "median" | sed 's/^/[r04z] /'
+    timeout 300 python tools/ab/knob_ab.py --rounds 4 "$OFF" 'fuse_final_sampler=False' 'graph_steps=8' 2>&1 | grep -E "median" | sed 's/^/[new ] /'
+  done | tee $OUT/${TAG}_lib_knob_ab.log
+  timeout 400 python tools/ab/knob_ab.py --batch 8 --steps 200 --rounds 3 'fuse_final_sampler=False' 'graph_steps=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fuse_b8.log
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
