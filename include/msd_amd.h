@@ -36,8 +36,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead, fuse_final_sampler
-                                      appended to msd_config.
+#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
                                    4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
                                       NO environment variable.  3: MSD_ERR_RANGE; distinct bfloat16-plane precisions */
@@ -169,9 +168,6 @@ typedef struct msd_config {
                                      many 128-key ring stages ahead of their LDS-DMA (they are HBM-cold at every
                                      step): 0 = the library's choice (2, with one song per handle; batched launches
                                      are bandwidth-bound and never touch), -1 = off, 1 .. 16 */
-  int32_t fuse_final_sampler;     /* the decoder's last (exact-fp32) projection runs inside the sampler update's launch
-                                     (both CFG passes of an element meet in one block; bit-identical, one launch less per
-                                     step): 0 = the library's choice (on), 1 = on, 2 = off */
 } msd_config;
 
 const char* msd_version(void);

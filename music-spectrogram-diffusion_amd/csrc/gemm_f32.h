@@ -10,7 +10,6 @@
 // guarded (M need not be a tile multiple); N % 64 == 0 and K % 16 == 0.
 #pragma once
 #include "common.h"
-#include "elementwise.h"
 
 namespace msd {
 
@@ -140,26 +139,28 @@ struct FinalProjParams {
 
 constexpr int kFinalProjWaves = 8;   // K is split over the waves of a block (latency-bound: M*N is tiny)
 
-// The block's RT row tiles (16 rows each, first rows rows0[i]) x 32 columns at n0: every wave accumulates its K slices,
-// the partial tiles land in red[wave][16 i + row][col]; rstd[16 i + row] = the rows' 1 / rms from the partial sums of
-// squares.  Ends with a barrier (red and rstd complete).
+// RT: 16-row MFMA tiles per block (block tile = 16*RT rows x 32 columns)
 template <int RT>
-__device__ __forceinline__ void final_proj_tiles(const FinalProjParams& p, const int (&rows0)[RT], int n0,
-                                                 float (*red)[16 * RT][33], float* rstd) {
+__global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(FinalProjParams p) {
+  warm_kernargs<kernarg_lines<FinalProjParams>()>();
+  constexpr int BMR = 16 * RT;
+  __shared__ __attribute__((aligned(16))) float red[kFinalProjWaves][BMR][33];
+  __shared__ float rstd[BMR];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.y * BMR, n0 = blockIdx.x * 32;   // grid (N / 32, M / BMR): no integer division at the entry
   const int g = lane >> 4, r = lane & 15;
-  // row statistics once per row: the 64 lanes of wave i take a quarter of a row's partial sums each (lane = quarter x
-  // row) for row tile i, all loads in flight together, two shuffles.  Round 3's form -- one thread per row, a run-time
-  // loop -- was 24 DEPENDENT global loads (vmcnt(0) behind each) that the whole block then waited for at its barrier:
-  // about 5 of this kernel's 10.6 us.  (tiles <= 32.)
+  // row statistics once per row: the 64 lanes of wave 0 take a quarter of a row's partial sums each (lane = quarter x
+  // row), all loads in flight together, two shuffles.  Round 3's form -- one thread per row, a run-time loop -- was 24
+  // DEPENDENT global loads (vmcnt(0) behind each) that the whole block then waited for at its barrier: about 5 of this
+  // kernel's 10.6 us.  (BMR <= 16 rows here; tiles <= 32.)
   float ss = 0.f;
-  float sv[8];   // issued here, reduced BEHIND the K loop: the wave's operand loads must not queue behind a wait for these
-  static_assert(RT <= kFinalProjWaves, "one wave per row tile for the statistics");
-  if (wave < RT) {
+  float sv[8];   // issued here, reduced BEHIND the K loop: wave 0's operand loads must not queue behind a wait for these
+  static_assert(BMR <= 16, "one wave covers the rows of the tile in quarters");
+  if (wave == 0) {
     const int row = lane & 15, part = lane >> 4;
     const int per = (p.tiles + 3) >> 2;                        // partial sums per quarter (<= 8)
-    const float* q = p.ssq + (size_t)(rows0[wave < RT ? wave : 0] + row) * p.tiles;
+    const float* q = p.ssq + (size_t)(m0 + (row < BMR ? row : 0)) * p.tiles;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int t = part * per + i;
@@ -174,9 +175,7 @@ __device__ __forceinline__ void final_proj_tiles(const FinalProjParams& p, const
   // one MFMA K-step is 4 wide: lane (g, r) holds A[row r][k0 + 4g .. +3] and B[k0 + 4g + c][col r];
   // a wave's slice is 16 wide (4 lane groups x 4), slices go round-robin over the waves; the
   // (HBM-cold) operand loads of U slices of a wave are issued together.
-  const float* xa[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) xa[i] = p.x + (size_t)(rows0[i] + r) * p.K + 4 * g;
+  const float* xa = p.x + (size_t)(m0 + r) * p.K + 4 * g;
   const float* wb = p.wg + (size_t)(4 * g) * p.N + n0 + r;
   constexpr int U = 6;   // K slices in flight per wave (768 / (16 * 8) = 6: one round at D = 768)
   for (int kb = wave * 16; kb < p.K; kb += 16 * kFinalProjWaves * U) {
@@ -187,7 +186,7 @@ __device__ __forceinline__ void final_proj_tiles(const FinalProjParams& p, const
       const int k0 = kb + u * 16 * kFinalProjWaves;
       const int kk = k0 < p.K ? k0 : kb;
 #pragma unroll
-      for (int i = 0; i < RT; ++i) a[u][i] = *reinterpret_cast<const float4*>(xa[i] + kk);
+      for (int i = 0; i < RT; ++i) a[u][i] = *reinterpret_cast<const float4*>(xa + (size_t)(i * 16) * p.K + kk);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -209,14 +208,14 @@ __device__ __forceinline__ void final_proj_tiles(const FinalProjParams& p, const
       }
     }
   }
-  if (wave < RT) {
+  if (wave == 0) {
     const int part = lane >> 4, per = (p.tiles + 3) >> 2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss += (i < per && part * per + i < p.tiles) ? sv[i] : 0.f;
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    if (lane < 16) rstd[wave * 16 + lane] = 1.0f / sqrtf(ss * p.inv_d + 1e-6f);
   }
+  if (threadIdx.x < BMR) rstd[threadIdx.x] = 1.0f / sqrtf(ss * p.inv_d + 1e-6f);
   // C layout: col = lane & 15, row = (lane >> 4) * 4 + e
 #pragma unroll
   for (int i = 0; i < RT; ++i)
@@ -225,91 +224,13 @@ __device__ __forceinline__ void final_proj_tiles(const FinalProjParams& p, const
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][i * 16 + g * 4 + e][j * 16 + r] = acc[i][j][e];
   __syncthreads();
-}
-
-// eps = rstd[m] * (sum of the waves' partial tiles): the ROUNDED product (the fused sampler below feeds it into the
-// sampler arithmetic where the stand-alone kernel stores it -- no contraction into what follows)
-template <int ROWS>
-__device__ __forceinline__ float final_proj_value(float (*red)[ROWS][33], const float* rstd, int m, int n) {
-#pragma clang fp contract(off)
-  float v = 0.f;
-#pragma unroll
-  for (int w = 0; w < kFinalProjWaves; ++w) v += red[w][m][n];
-  return v * rstd[m];
-}
-
-// RT: 16-row MFMA tiles per block (block tile = 16*RT consecutive rows x 32 columns)
-template <int RT>
-__global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_f32_kernel(FinalProjParams p) {
-  warm_kernargs<kernarg_lines<FinalProjParams>()>();
-  constexpr int BMR = 16 * RT;
-  __shared__ __attribute__((aligned(16))) float red[kFinalProjWaves][BMR][33];
-  __shared__ float rstd[BMR];
-  const int m0 = blockIdx.y * BMR, n0 = blockIdx.x * 32;   // grid (N / 32, M / BMR): no integer division at the entry
-  int rows0[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) rows0[i] = m0 + 16 * i;
-  final_proj_tiles<RT>(p, rows0, n0, red, rstd);
   for (int item = threadIdx.x; item < BMR * 32; item += 64 * kFinalProjWaves) {
     const int m = item >> 5, n = item & 31;
-    p.out[(size_t)(m0 + m) * p.N + n0 + n] = final_proj_value<BMR>(red, rstd, m, n);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFinalProjWaves; ++w) v += red[w][m][n];
+    p.out[(size_t)(m0 + m) * p.N + n0 + n] = v * rstd[m];
   }
-}
-
-// The decoder's last projection AND the sampler update in one launch (round 5): block (n0, m0) projects rows m0 .. m0 +
-// 15 of EVERY CFG pass (row tile i = pass i: rows m0 + i * pass_rows) and the 512 threads then run eval_step.body's
-// element arithmetic (elementwise.h sampler_update) on the 16 x 32 outputs -- both passes of an element are in the
-// block, so eps never goes through memory and the step loses a launch.  Same arithmetic in the same order as
-// final_proj_f32_kernel + sampler_step_kernel: bit-identical (tests/test_gpu_fused_ops.py).
-template <int P, int MODE>
-__global__ void __launch_bounds__(64 * kFinalProjWaves) final_proj_sampler_kernel(FinalProjParams p, SamplerParams sp,
-                                                                                  int pass_rows) {
-  warm_kernargs<kernarg_lines<FinalProjParams, SamplerParams, int>()>();
-  constexpr int BMR = 16 * P;
-  __shared__ __attribute__((aligned(16))) float red[kFinalProjWaves][BMR][33];
-  __shared__ float rstd[BMR];
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
-  int rows0[P];
-#pragma unroll
-  for (int i = 0; i < P; ++i) rows0[i] = m0 + i * pass_rows;
-  // what the sampler needs besides eps does not depend on the projection: request it first
-  const int i_step = sp.step_ptr[1];   // (published by the step's first launch, EpiInProj)
-  const int m = threadIdx.x >> 5, n = threadIdx.x & 31;
-  const size_t idx = (size_t)(m0 + m) * p.N + n0 + n;
-  static_assert(kCoefCount == 20, "five 16-byte loads per row");
-  f32x4 cr[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) cr[k] = reinterpret_cast<const f32x4*>(sp.coef + (size_t)i_step * kCoefCount)[k];
-  const float zz = sp.z[idx];
-  float nz = 0.f;
-  if (!sp.ddim && i_step != 0) nz = (*sp.noise_slot)[(size_t)i_step * sp.n + idx];
-  final_proj_tiles<P>(p, rows0, n0, red, rstd);
-  float c[kCoefCount];
-#pragma unroll
-  for (int k = 0; k < kCoefCount; ++k) c[k] = cr[k >> 2][k & 3];
-  const float ec = final_proj_value<BMR>(red, rstd, m, n);
-  const float eu = P == 2 ? final_proj_value<BMR>(red, rstd, 16 + m, n) : 0.f;
-  const float out = sampler_update<MODE>(sp, c, i_step, zz, ec, eu, nz);
-  sp.z[idx] = out;
-  if (sp.z_hi) {
-    RangeCheck rc;
-    rc.see(out);
-    h16_t h, l;
-    split_h16(out, h, l);
-    sp.z_hi[idx] = h;
-    if (sp.z_lo) sp.z_lo[idx] = l;
-    rc.commit(sp.sat, sp.sat_tag);
-  }
-  // the scan index: every block read slot 1; slot 0 is the next step's (sampler_step_kernel does the same)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sp.step_ptr[0] = i_step - 1;
-}
-
-template <int P>
-inline void launch_final_proj_sampler(const FinalProjParams& fp, const SamplerParams& sp, int pass_rows, hipStream_t s) {
-  const dim3 grid(fp.N / 32, pass_rows / 16), block(64 * kFinalProjWaves);
-  if (sp.model_output == kOutX0) hipLaunchKernelGGL((final_proj_sampler_kernel<P, kOutX0>), grid, block, 0, s, fp, sp, pass_rows);
-  else if (sp.model_output == kOutV) hipLaunchKernelGGL((final_proj_sampler_kernel<P, kOutV>), grid, block, 0, s, fp, sp, pass_rows);
-  else hipLaunchKernelGGL((final_proj_sampler_kernel<P, kOutEps>), grid, block, 0, s, fp, sp, pass_rows);
 }
 
 // wg[k][n] = gamma[k] * w[k][n]

@@ -158,7 +158,6 @@ struct msd_model {
   int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
-  bool fuse_final_sampler = true;   // enqueue_step; msd_config.fuse_final_sampler = 2 turns it off (A/B, bitwise tests)
   int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
@@ -971,15 +970,8 @@ inline int cross_split(const msd_model* m, int batch, int e) {
   return ks;
 }
 
-inline FinalProjParams final_proj_params(const msd_model* m, int M) {
-  FinalProjParams fp;
-  fp.x = m->x; fp.wg = m->w_out_g; fp.ssq = m->ssq; fp.out = m->eps;
-  fp.M = M; fp.N = m->ND; fp.K = m->D; fp.tiles = m->D / kNarrowTile; fp.inv_d = 1.0f / (float)m->D;
-  return fp;
-}
-
 template <int NP>
-void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false, bool with_final = true) {
+void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
   // P passes of `batch` songs: rows [0, BT) are the conditional pass when `cond0`, rows [BT, 2 BT) the unconditional one.
   // `dedup0` (a CFG step: P == 2, cond0; the input projection wrote pass 0 only): S5 -- up to layer 0's first
   // cross-attention both passes hold the same rows (same z, same FiLM, same self-attention: models.py:373-386,
@@ -1105,9 +1097,10 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false, b
   // with a gain of up to 22026 at the first steps, and with 2^-16 products the short-chain
   // parity tests show 40x more clip-boundary outliers.  Parity mode therefore runs it on the
   // exact-fp32 MFMA; the plain bf16 mode uses the folded bf16 GEMM like its other layers.
-  if (!with_final) return;   // (enqueue_step: the projection runs inside the sampler's launch, final_proj_params)
   if (NP == 2) {
-    const FinalProjParams fp = final_proj_params(m, M);
+    FinalProjParams fp;
+    fp.x = x; fp.wg = m->w_out_g; fp.ssq = ssq; fp.out = eps;
+    fp.M = M; fp.N = m->ND; fp.K = D; fp.tiles = tiles; fp.inv_d = 1.0f / (float)D;
     c.begin(KC_FINAL_PROJ);
     hipLaunchKernelGGL(final_proj_f32_kernel<1>, dim3(m->ND / 32, M / 16), dim3(64 * kFinalProjWaves), 0, c.s, fp);
     c.end(KC_FINAL_PROJ);
@@ -1143,11 +1136,8 @@ void enqueue_step(Ctx& c, int batch) {
   const int P = m->passes;
   // S5: a CFG step computes layer 0's self-attention block once for both passes
   const bool dedup0 = P == 2 && m->dedup_layer0;
-  // the decoder's last projection runs inside the sampler's launch (gemm_f32.h final_proj_sampler_kernel; exact-fp32
-  // projection = the two-plane modes; one launch less per step, bit-identical)
-  const bool fused_tail = NP == 2 && m->fuse_final_sampler && (P == 1 || P == 2);
   in_proj<NP>(c, batch, dedup0 ? 1 : P, /*publish_step=*/true);
-  decoder_layers<NP>(c, batch, P, true, dedup0, /*with_final=*/!fused_tail);
+  decoder_layers<NP>(c, batch, P, true, dedup0);
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
@@ -1157,16 +1147,8 @@ void enqueue_step(Ctx& c, int batch) {
   sp.z_hi = m->zp.p[0];
   sp.z_lo = m->NP == 2 ? m->zp.p[1] : nullptr;
   sp.sat = m->d_sat; sp.sat_tag = (unsigned)KC_SAMPLER + 1u;
-  sp.step_from_slot1 = 1;
-  if (fused_tail) {
-    const FinalProjParams fp = final_proj_params(m, P * batch * m->T);
-    c.begin(KC_FINAL_PROJ);
-    if (P == 2) launch_final_proj_sampler<2>(fp, sp, batch * m->T, c.s);
-    else launch_final_proj_sampler<1>(fp, sp, batch * m->T, c.s);
-    c.end(KC_FINAL_PROJ);
-    return;
-  }
   c.begin(KC_SAMPLER);
+  sp.step_from_slot1 = 1;
   launch_sampler_step(sp, c.s);
   c.end(KC_SAMPLER);
 }
@@ -1239,7 +1221,6 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->cross_key_split != 0 && cfg->cross_key_split != 1 && cfg->cross_key_split != 2 && cfg->cross_key_split != 4 &&
       cfg->cross_key_split != 8) return bad("cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8");
   if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
-  if (cfg->fuse_final_sampler < 0 || cfg->fuse_final_sampler > 2) return bad("fuse_final_sampler must be 0 (library default), 1 (on) or 2 (off)");
   if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
@@ -1256,7 +1237,6 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
   m->dedup_layer0 = cfg->dedup_layer0 != 2;
   if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
-  m->fuse_final_sampler = cfg->fuse_final_sampler != 2;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-

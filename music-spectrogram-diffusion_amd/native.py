@@ -89,7 +89,7 @@ class MsdConfig(ctypes.Structure):
       ('attn_q_planes', ctypes.c_int32), ('attn_p_planes', ctypes.c_int32), ('graph_steps', ctypes.c_int32),
       ('weight_prefetch', ctypes.c_int32),
       ('dedup_layer0', ctypes.c_int32), ('cross_key_split', ctypes.c_int32), ('keep_raw_weights', ctypes.c_int32),
-      ('kv_touch_ahead', ctypes.c_int32), ('fuse_final_sampler', ctypes.c_int32)]
+      ('kv_touch_ahead', ctypes.c_int32)]
 
 
 # msd_config only ever grows at its end, so an OLDER library can be driven by passing it the struct size it knows

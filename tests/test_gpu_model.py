@@ -548,7 +548,6 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
     dedup_layer0        S5: in a CFG step decoder layer 0's QKV / self-attention / attention-out run on the conditional
                         pass's rows only and the attention-out epilogue writes every row twice -- both passes hold the
                         same rows up to the first cross-attention (models/diffusion/models.py:373-386, network.py:174-193)
-    fuse_final_sampler  the decoder's last projection inside the sampler update's launch (gemm_f32.h)
     kv_touch_ahead      the cross-attention's prefetch wave touches K / V^T lines ahead of their LDS-DMA (attention.h)
   One and two songs per handle."""
   from oracle import philox
@@ -561,7 +560,7 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
     init_z, noise = philox.segment_noise((nb, t, 128), steps, seed=5, segment=0)
     outs = {}
     for name, kw in (('default', {}), ('dedup_layer0 off', dict(dedup_layer0=False)),
-                     ('fuse_final_sampler off', dict(fuse_final_sampler=False)), ('kv_touch_ahead off', dict(kv_touch_ahead=0)),
+                     ('kv_touch_ahead off', dict(kv_touch_ahead=0)),
                      ('kv_touch_ahead 5', dict(kv_touch_ahead=5))):
       model = msd_amd.InferenceModel(params, spec, batch_size=nb, **kw, **helpers.ALL_PLANES)
       got, _ = model.predict(batch, init_z=init_z, noise=noise)
@@ -570,28 +569,6 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
     assert np.isfinite(outs['default']).all()
     for name, got in outs.items():
       assert np.array_equal(got, outs['default']), (preset, nb, name, np.abs(got - outs['default']).max())
-
-
-@pytest.mark.parametrize('model_output', ['eps', 'x0', 'v'])
-@pytest.mark.parametrize('sampler,cfg_weight', [('ddpm', 5.0), ('ddpm', 1.0), ('ddim', 5.0)])
-def test_fused_projection_and_sampler_in_every_sampler_mode(model_output, sampler, cfg_weight):
-  """final_proj_sampler_kernel against final_proj_f32_kernel + sampler_step_kernel in every branch of eval_step.body the
-  sampler kernel is specialised for (model output eps / x0 / v, DDPM / DDIM, one or two CFG passes): bit-identical."""
-  import dataclasses
-  spec = msd_amd.config.preset('tiny_context', num_steps=6, cfg_weight=cfg_weight)
-  d = spec.diffusion
-  spec = dataclasses.replace(spec, diffusion=dataclasses.replace(
-      d, model_output=model_output, sampler=dataclasses.replace(d.sampler, name=sampler)))
-  params = msd_amd.synthetic.init_params(spec, 4, norm_scale_jitter=0.1)
-  batch = helpers.make_batch(spec, batch=2, ctx_mask='ragged')
-  init_z, noise = helpers.make_noise(spec, batch=2)
-  outs = []
-  for fuse in (None, False):
-    model = msd_amd.InferenceModel(params, spec, batch_size=2, fuse_final_sampler=fuse, **helpers.ALL_PLANES)
-    got, _ = model.predict(batch, init_z=init_z, noise=None if sampler == 'ddim' else noise)
-    outs.append(np.asarray(got))
-    del model
-  assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
 
 
 def test_staging_copies_of_packed_weights_are_freed():

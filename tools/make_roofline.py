@@ -62,9 +62,15 @@ def classify(name, step_kernels=None):
   # one, so in a trace that holds a 32 x 48 instantiation the 64 x 32 / 32 x 32 residual templates are attention-out /
   # cross-out (one class each); older traces keep round 3's meaning (the table below)
   if step_kernels is not None and any('32, 48, 4' in k for k in step_kernels) and 'EpiResidualNorm' in name:
+    # round 5: layer 0's self-attention block runs on one CFG pass's rows (S5): its out-projection is the duplicating
+    # epilogue EpiResidualNorm<2, true> on 32 x 32 tiles (M = 256) -- a class of its own, one launch per step
+    if 'EpiResidualNorm<2, true>' in name:
+      return 'gemm_attn_out_l0'
     for sub, cls in (('32, 48, 4', 'gemm_mlp_out'), ('64, 32, 4', 'gemm_attn_out'), ('32, 32, 4', 'gemm_cross_out')):
       if sub in name:
         return cls
+  if step_kernels is not None and 'EpiQKV' in name and '64, 64, 3' in name and any('64, 96, 3' in k and 'EpiQKV' in k for k in step_kernels):
+    return 'gemm_qkv_l0'      # layer 0's QKV projection on M = 256 rows (S5): 64 x 64 tiles, one launch per step
   for sub, cls in CLASS:
     if sub in name:
       return cls
@@ -99,6 +105,10 @@ def main():
   # (M = T, K = D + J); with it the 32 x 32 residual template only serves the cross-attention output projection
   flops['gemm_attn_out+cross_q'] = flops['gemm_attn_out'] + flops['gemm_cross_q']          # ALGORITHMIC: 2 T J D once
   abytes['gemm_attn_out+cross_q'] = abytes['gemm_attn_out'] + abytes['gemm_cross_q']
+  flops1, abytes1 = bench.class_flops(spec, s_valid, 1), bench.class_bytes(spec, s_valid, 1)
+  for c in ('gemm_qkv', 'gemm_attn_out'):   # layer 0's launches on ONE pass's rows (round 5, S5)
+    flops[c + '_l0'] = flops1[c]
+    abytes[c + '_l0'] = abytes1[c]
   flops.setdefault('attn_cross_merge', 0.0)
   flops.setdefault('sampler_step', 0.0)
   # a class may run as several instantiations (with / without the weight prefetch): call-weighted means
@@ -165,6 +175,8 @@ def main():
       e['algorithmic_bytes'] = int(abytes['gemm_cross_out'])
       e['waste'] = round(e['fabric_bytes_per_launch'] / abytes['gemm_cross_out'], 2)
   launches = {'gemm_attn_out+gemm_cross_out': 12 if hoisted else 24, 'final_proj_f32': 1, 'in_proj_f32': 1, 'sampler_step': 1}
+  if 'gemm_qkv_l0' in out:   # round 5: layer 0's self-attention block has classes of its own (attention: same kernel, 12 launches)
+    launches.update({'gemm_qkv_l0': 1, 'gemm_attn_out_l0': 1, 'gemm_qkv': 11, 'gemm_attn_out': 11})
   step_us = sum(e['avg_us'] * launches.get(c, 12) for c, e in out.items())
   step_fabric = sum(e.get('fabric_bytes_per_launch', 0) * launches.get(c, 12) for c, e in out.items())
   step_alg = sum(e.get('algorithmic_bytes', 0) * launches.get(c, 12) for c, e in out.items())
