@@ -64,6 +64,11 @@ fifth)   # fused projection + sampler: bitwise tests in every sampler mode; the 
   done | tee $OUT/${TAG}_lib_knob_ab.log
   timeout 400 python tools/ab/knob_ab.py --batch 8 --steps 200 --rounds 3 'fuse_final_sampler=False' 'graph_steps=8' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fuse_b8.log
   ;;
+sixth)   # touch-ahead of the NEXT cross-attention launch's entry stages: bitwise tests, then in-process A/B
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "exact_launch or staging" > $OUT/${TAG}_exact_tests.log 2>&1; tail -4 $OUT/${TAG}_exact_tests.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_touch_next_ab.json 'kv_touch_ahead=0' 'kv_touch_ahead=102' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_next_ab.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --tokens 300 --tokens 900 --json $OUT/${TAG}_touch_next_ab2.json 'kv_touch_ahead=0' 'kv_touch_ahead=102' 'kv_touch_ahead=2' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_next_ab2.log
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
