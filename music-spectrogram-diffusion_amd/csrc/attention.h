@@ -59,11 +59,6 @@ struct AttnParams {
   int qp = 0;                // query-side single-plane switches (attention_kernel QP bits 0 / 1), NP = 2 only
   int touch_ahead = 0;       // > 0 (launches with a prefetch wave only): that wave also touches the K / V^T lines of the
                              // block's ring stages this many stages AHEAD of their LDS-DMA (kv_touch_ahead below)
-  int touch_next = 0;        // ... and the first NS stages of the NEXT cross-attention launch's K / V^T (the next decoder
-  long long next_k_off = 0;  // layer's cache; the last layer's launch names layer 0's, for the next DDPM step): element
-  long long next_vt_off = 0; // offsets from k[] / vt[] to that launch's.  Those stages are what a cross-attention block
-                             // otherwise waits 3.5 us for at its entry (HBM-cold); touched ~80 us early they wait in the
-                             // memory-side cache
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -129,7 +124,7 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   // one stage = per plane 128 K rows of 128 bytes + 64 V^T rows of 256 bytes = 256 lines: 4 wave-wide touches per plane
-  auto touch_stage = [&](int st, long long k_off = 0, long long vt_off = 0) {
+  auto touch_stage = [&](int st) {
     const int kb = (ks + st * p.ksplit) * kAttStageKeys;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
@@ -140,12 +135,12 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
         if (u < 2) {           // K rows kb + tt
           int row = kb + tt;
           row = row < last_row ? row : last_row;
-          src = p.k[pl] + k_off + (size_t)seg * p.k_seg_stride + (size_t)row * p.ldk + head * 64;
+          src = p.k[pl] + (size_t)seg * p.k_seg_stride + (size_t)row * p.ldk + head * 64;
         } else {               // V^T rows d = (tt - 128) / 2, half = tt & 1 (64 keys = 128 bytes each)
           const int d = (tt - 128) >> 1;
           int col = kb + (tt & 1) * 64;
           col = col < last_kcol ? col : last_kcol;
-          src = p.vt[pl] + vt_off + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64 + d) * p.vt_ld + col;
+          src = p.vt[pl] + (size_t)seg * p.vt_seg_stride + (size_t)(head * 64 + d) * p.vt_ld + col;
         }
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)sink_lds, 4, 0, 0);
       }
@@ -156,10 +151,6 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     prefetch_wave<PF, true>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], sink_lds);
   }
-  // the next launch's entry stages (same head, same split, same song: the same key counts), once per (head, split):
-  // from the block of query tile 0
-  if (p.touch_next && (blockIdx.y >> kl2) == 0)
-    for (int st = 0; st < NS && st < nst; ++st) touch_stage(st, p.next_k_off, p.next_vt_off);
   {
     for (int st = 0; st < nst; ++st) {
       __builtin_amdgcn_s_barrier();                 // the compute waves' barrier of stage st

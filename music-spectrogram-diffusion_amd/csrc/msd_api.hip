@@ -158,7 +158,6 @@ struct msd_model {
   int graph_steps = 8;              // DDPM steps per graph launch (msd_config.graph_steps; 1 -> 4 -> 10: 1.2000 -> 1.1963 -> 1.1955 ms/step)
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
-  bool kv_touch_next = true;   // ... and the next cross-attention launch's entry stages (msd_config.kv_touch_ahead >= 100: off, A/B)
   int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
@@ -542,8 +541,7 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1,
-               long long next_k_off = 0, long long next_vt_off = 0) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -563,9 +561,6 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   // 2 songs +1.1 %, 4 songs +3.5 %, 8 songs +3.1 % -- batched launches are bandwidth-bound and the touches only add
   // requests -- so the library turns it on for one song only, whatever msd_config.kv_touch_ahead asks for beyond that.
   p.touch_ahead = (kc == KC_ATTN_CROSS && segs == 1) ? c.m->kv_touch_ahead : 0;
-  // ... and, with it, the entry stages of the NEXT cross-attention launch's cache (attention.h touch_next)
-  p.touch_next = p.touch_ahead > 0 && (next_k_off != 0 || next_vt_off != 0) && c.m->kv_touch_next;
-  p.next_k_off = next_k_off; p.next_vt_off = next_vt_off;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -1066,11 +1061,9 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
         const int region = cross_region(m, e), ks = cross_split(m, batch, e);
         const bool warm_mlp_in = e + 1 == m->n_cross;
         const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
-        // the same module of the next layer (layer 0's for the last: next step) -- for the touch-ahead of its entry stages
-        const long long to_next = m->n_cross == 1 ? ((long long)((l + 1) % m->Ld) - l) * (long long)m->Bmax * m->S_pad * J : 0;
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
-                      batch, ks, region, &pf, -1, to_next, to_next);
+                      batch, ks, region, &pf);
       }
       // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
       // other; the last one also writes the folded-norm inputs of the MLP block
@@ -1228,8 +1221,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->cross_key_split != 0 && cfg->cross_key_split != 1 && cfg->cross_key_split != 2 && cfg->cross_key_split != 4 &&
       cfg->cross_key_split != 8) return bad("cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8");
   if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
-  if (cfg->kv_touch_ahead < -1 || (cfg->kv_touch_ahead > 16 && cfg->kv_touch_ahead < 101) || cfg->kv_touch_ahead > 116)
-    return bad("kv_touch_ahead must be 0 (library default), -1 (off), 1 .. 16 stages, or 100 + stages (this launch's stages only)");
+  if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1244,10 +1236,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->graph_steps > 0) m->graph_steps = cfg->graph_steps;
   if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
   m->dedup_layer0 = cfg->dedup_layer0 != 2;
-  if (cfg->kv_touch_ahead) {
-    m->kv_touch_next = cfg->kv_touch_ahead < 100;
-    m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead % 100;
-  }
+  if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-

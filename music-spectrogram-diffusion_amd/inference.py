@@ -168,8 +168,8 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
     raise ValueError('cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8')
   cfg.cross_key_split = int(cross_key_split)
   cfg.keep_raw_weights = int(bool(keep_raw_weights))
-  if kv_touch_ahead is not None and not (0 <= int(kv_touch_ahead) <= 16 or 101 <= int(kv_touch_ahead) <= 116):
-    raise ValueError('kv_touch_ahead must be None (library default), 0 (off), 1 .. 16 stages, or 100 + stages')
+  if kv_touch_ahead is not None and not 0 <= int(kv_touch_ahead) <= 16:
+    raise ValueError('kv_touch_ahead must be None (library default), 0 (off) or 1 .. 16 stages')
   cfg.kv_touch_ahead = 0 if kv_touch_ahead is None else (-1 if int(kv_touch_ahead) == 0 else int(kv_touch_ahead))
   return cfg
 

@@ -561,7 +561,7 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
     outs = {}
     for name, kw in (('default', {}), ('dedup_layer0 off', dict(dedup_layer0=False)),
                      ('kv_touch_ahead off', dict(kv_touch_ahead=0)),
-                     ('kv_touch_ahead 5', dict(kv_touch_ahead=5)), ('kv_touch_ahead 2, this launch only', dict(kv_touch_ahead=102))):
+                     ('kv_touch_ahead 5', dict(kv_touch_ahead=5))):
       model = msd_amd.InferenceModel(params, spec, batch_size=nb, **kw, **helpers.ALL_PLANES)
       got, _ = model.predict(batch, init_z=init_z, noise=noise)
       outs[name] = np.asarray(got)
