@@ -77,6 +77,16 @@ final)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
   bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile.log 2>&1; tail -4 $OUT/${TAG}_profile.log
+  TS=$ROOT/tools/ab/libs/libmsd_amd_ts.so   # the same sources with -DMSD_TIMESTAMPS=1 (tools/README.md)
+  if [ -f $TS ]; then
+    MSD_AMD_LIB=$TS timeout 200 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times.txt 2>&1; tail -3 $OUT/${TAG}_phase_times.txt
+    BATCH=8 MSD_AMD_LIB=$TS timeout 300 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times_b8.txt 2>&1; tail -3 $OUT/${TAG}_phase_times_b8.txt
+  fi
+  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b8
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b8 -- \
+      python $ROOT/bench.py --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 > $OUT/${TAG}_bench_b8_under_rocprof.json 2>/dev/null
+  find /tmp/prof_b8 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_b8_kernel_stats.csv
+  cd $ROOT
   timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 1500 $OUT/${TAG}_bench_default.json
   ;;
 esac
