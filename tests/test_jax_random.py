@@ -51,3 +51,35 @@ def test_normal_distribution_and_erfinv():
   assert noise.shape == (5, 1, 8, 16)
   np.testing.assert_array_equal(init_z, jr.normal(jr.prng_key(3), (1, 8, 16)))
   np.testing.assert_array_equal(noise[2], jr.normal(jr.fold_in(jr.prng_key(3), 2), (1, 8, 16)))
+
+
+def test_float_stage_against_scipy_and_torch_erfinv():
+  """External pin for N5's FLOAT stage (round 5): the Giles polynomial `erfinv_f32` restates XLA's float32 ErfInv; what
+  it must compute is erf^-1.  Checked against scipy.special.erfinv (float64) and torch.erfinv (an independent float32
+  implementation) over the whole range the uniform stage can produce -- every float32 step near +-1 included, where
+  the draw's magnitude is largest: <= 1e-6 relative in the core and <= 2e-5 in the tails (the accuracy of the float32 formula itself), i.e.
+  the restated constants and the two-branch structure are right.  (XLA's own rounding of the same polynomial may
+  differ from NumPy's by an ulp: `normal` is seed-compatible to ~1e-7, as the module says.)"""
+  import scipy.special
+  import torch
+  lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
+  grid = np.concatenate([
+      np.linspace(lo, np.float32(1.0) - np.float32(2.0 ** -24), 200001, dtype=np.float64).astype(np.float32),
+      np.float32(1.0) - np.float32(2.0 ** -24) * np.arange(1, 4000, dtype=np.float32),      # the last float32 steps below 1
+      lo + np.float32(2.0 ** -24) * np.arange(0, 4000, dtype=np.float32)])                  # ... and above -1
+  grid = grid[(grid > -1) & (grid < 1)]
+  got = jr.erfinv_f32(grid).astype(np.float64)
+  want = scipy.special.erfinv(grid.astype(np.float64))
+  rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+  core = np.abs(grid) < 0.9
+  # float32 evaluation of w = -log1p(-x^2) loses bits as |x| -> 1 (1 - x^2 cancels): a few ulp in the core, ~1e-5 in
+  # the tails -- a property of the float32 formula XLA evaluates too, not of this restatement
+  assert rel[core & (np.abs(grid) > 1e-3)].max() <= 1e-6 and rel.max() <= 2e-5, (rel[core].max(), rel.max(), grid[np.argmax(rel)])
+  t = torch.erfinv(torch.as_tensor(grid)).numpy().astype(np.float64)
+  rel_t = np.abs(got - t) / np.maximum(np.abs(t), 1e-30)
+  assert rel_t[core & (np.abs(grid) > 1e-3)].max() <= 2e-6 and rel_t.max() <= 4e-5
+  # the uniform stage: [nextafter(-1, 0), 1) exactly, monotone in the 23 mantissa bits it keeps
+  bits = np.array([0, 1 << 9, 0x7FFFFFFF, 0xFFFFFE00, 0xFFFFFFFF], np.uint32)
+  floats = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+  u = np.maximum(lo, floats * np.float32(np.float32(1.0) - lo) + lo)
+  assert u[0] == lo and u.max() < 1.0 and (np.diff(u[[0, 1, 2, 3]]) > 0).all() and u[3] == u[4]
