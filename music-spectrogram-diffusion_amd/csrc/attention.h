@@ -57,6 +57,7 @@ struct AttnParams {
   unsigned* sat = nullptr;   // half-plane range flag of the handle (common.h RangeCheck)
   unsigned sat_tag = 1;
   int qp = 0;                // query-side single-plane switches (attention_kernel QP bits 0 / 1), NP = 2 only
+  int allow_qb4 = 0;         // host only: this launch may run on 128-row blocks (attention_query_blocks)
   int touch_ahead = 0;       // > 0 (launches with a prefetch wave only): that wave also touches the K / V^T lines of the
                              // block's ring stages this many stages AHEAD of their LDS-DMA (kv_touch_ahead below)
 };
@@ -85,7 +86,20 @@ constexpr int attention_work_smem() {
              : QB * kAttKG * kAttWStride * 4;
 }
 template <int NP, int NS, int QB>
-constexpr int attention_smem() { return attention_work_smem<NP, NS, QB>() + kAttTouchSink; }
+constexpr int attention_smem() { return attention_work_smem<NP, NS, QB>() + (QB < 4 ? kAttTouchSink : 0); }   // (QB = 4: the 160 KiB are full; no prefetch wave there)
+
+// Query blocks per workgroup for a launch of `blocks64` 64-row blocks (heads x query tiles x key splits x segments):
+//   < 128 blocks           -> 32-row blocks (QB = 1): twice as many, when most of the 256 CUs would be idle
+//   one round of the chip  -> 64-row blocks (QB = 2): K / V traffic halves
+//   more than one round    -> 128-row blocks (QB = 4, 16 waves; round 5): the batched cross-attention is latency-bound on
+//                             its two-stage ring (2.5 - 3 us per stage, whatever the rows), so 12 x 4 x songs blocks in 1.5
+//                             rounds (8 songs: 384) cost 1.5 block lifetimes where 192 blocks of 128 rows cost one; no
+//                             prefetch wave fits beside 16 waves -- the host gives the launch's weight target to a neighbour
+__host__ __device__ inline int attention_query_blocks(int blocks64, int q_rows_per_seg, int np) {
+  if (blocks64 < 128) return 1;
+  if (np == 2 && blocks64 > 256 && q_rows_per_seg % 128 == 0) return 4;
+  return 2;
+}
 
 // QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
 // QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
@@ -164,6 +178,7 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
 
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
+  static_assert(QB < 4 || PF == kPfNone, "16 compute waves fill the workgroup: no prefetch wave");
   warm_kernargs<kernarg_lines<AttnParams>()>();
   if constexpr (kPfWaveAttn && PF != kPfNone) {
     if (threadIdx.x >= QB * kAttKG * 64) {   // the prefetch wave: a later GEMM's weights (+ this block's later K / V^T stages)
@@ -546,8 +561,10 @@ inline hipError_t attention_prepare_one() {
   if (smem < 64 * 1024) return hipSuccess;
   const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone, QP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? 1 : 0, QP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipError_t b = hipSuccess;
+  if constexpr (QB < 4)
+    b = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, NP == 2 ? 1 : 0, QP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   return a != hipSuccess ? a : b;
 }
 
@@ -562,6 +579,7 @@ inline hipError_t attention_prepare() {
   MSD_ATT_PREP(1, 0) MSD_ATT_PREP(2, 0)
   if constexpr (NP == 2) {
     MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3)
+    MSD_ATT_PREP(4, 0) MSD_ATT_PREP(4, 1) MSD_ATT_PREP(4, 2) MSD_ATT_PREP(4, 3)
   }
 #undef MSD_ATT_PREP
   return e;
@@ -578,7 +596,15 @@ inline void launch_attention_qp(const AttnParams& p, int heads, int segs, hipStr
   constexpr int PFW = NP == 2 ? 1 : 0;   // attention launches carry at most one target
   const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
-  if (blocks64 < 128) {
+  const int qb = attention_query_blocks(p.allow_qb4 ? blocks64 : (blocks64 > 256 ? 256 : blocks64), p.q_rows_per_seg, NP);
+  if constexpr (NP == 2) {
+    if (qb == 4) {   // (no prefetch wave: the caller moved the launch's weight target elsewhere -- msd_api.hip)
+      const dim3 g4(heads, (p.q_rows_per_seg / 128) * p.ksplit, segs);
+      hipLaunchKernelGGL((attention_kernel<NP, NS, 4, kPfNone, QP>), g4, dim3(4 * kAttKG * 64), (attention_smem<NP, NS, 4>()), stream, p);
+      return;
+    }
+  }
+  if (qb == 1) {
     if (pfw) hipLaunchKernelGGL((attention_kernel<NP, NS, 1, PFW, QP>), g1, dim3(kAttKG * 64 + (kPfWaveAttn && PFW ? 64 : 0)), smem1, stream, p);
     else hipLaunchKernelGGL((attention_kernel<NP, NS, 1, kPfNone, QP>), g1, dim3(kAttKG * 64), smem1, stream, p);
   } else {

@@ -561,6 +561,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   // 2 songs +1.1 %, 4 songs +3.5 %, 8 songs +3.1 % -- batched launches are bandwidth-bound and the touches only add
   // requests -- so the library turns it on for one song only, whatever msd_config.kv_touch_ahead asks for beyond that.
   p.touch_ahead = (kc == KC_ATTN_CROSS && segs == 1) ? c.m->kv_touch_ahead : 0;
+  p.allow_qb4 = kc == KC_ATTN_CROSS;   // (batched cross-attention: 128-row blocks, attention.h attention_query_blocks)
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -955,7 +956,9 @@ inline int cross_split(const msd_model* m, int batch, int e) {
     // ... but 2 on a long key axis: 12 x 4 x songs blocks of ~10 ring stages each are 1.5 rounds over the 256 CUs at 8
     // songs; halves of them pack better than the merge launch costs (ms per 300 / 200 steps, split 1 -> 2: 4 songs 759.7 ->
     // 752.4, 8 songs 782.4 -> 777.5; split 4 at 8 songs: 806.3; profiles/r05c_split_b8.log, r05c_touch_b4.log)
-    if (want < 2 && cross_keys_max(m, batch, e) > 6 * kAttStageKeys) want = 2;
+    // -- as long as the unsplit launch is at most one round of 64-row blocks: beyond that the launcher goes to 128-row
+    // blocks instead (attention.h attention_query_blocks) and a split would only undo that
+    if (want < 2 && blocks <= 256 && cross_keys_max(m, batch, e) > 6 * kAttStageKeys) want = 2;
     // the key split pays only on a long key axis (the 256-frame context region runs unsplit) ...
     const int cap = region >= 1024 ? 4 : (region >= 512 ? 2 : 1);
     want = std::min(want, cap);
@@ -1052,6 +1055,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
         const WeightPrefetch pf = prefetch_of<NP>(m, w.wo_cross[e], D, J);
         gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_Q, y, D, w.wq_cross[e], D, BT, J, D, es, 0, &pf);
       }
+      bool mlp_in_on_cross_out = false;
       for (int e = 0; e < m->n_cross; ++e) {
         const size_t r0 = (size_t)m->key_off[e];
         const h16_t* kc[2] = {m->kc.p[0] + loff + r0 * J, m->kc.p[NP - 1] + loff + r0 * J};
@@ -1059,7 +1063,11 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
         vt.p[0] = m->vtc.p[0] + loff + r0;
         vt.p[1] = NP == 2 ? m->vtc.p[1] + loff + r0 : nullptr;
         const int region = cross_region(m, e), ks = cross_split(m, batch, e);
-        const bool warm_mlp_in = e + 1 == m->n_cross;
+        // MLP-in's weights ride on the last module's attention launch -- unless that runs 16 compute waves per block
+        // (128-row blocks at batch: no room for a prefetch wave); its output projection carries them then
+        const bool qb4 = attention_query_blocks(m->H * (T / 64) * ks * batch, T, NP) == 4;
+        const bool warm_mlp_in = e + 1 == m->n_cross && !qb4;
+        if (e + 1 == m->n_cross && qb4) mlp_in_on_cross_out = true;
         const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
         attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
@@ -1073,7 +1081,8 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
         ec.g_lo = last_mod ? g_tab(2 * l + 1) : nullptr; ec.g_lo_stride = last_mod ? slots * D : 0;
         ec.g_hi = nullptr; ec.g_hi_stride = 0;
         ec.split_row = BT;
-        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, e == 0 ? ao : m->ao2, J, w.wo_cross[e], J, BT, D, J, ec);
+        const WeightPrefetch pf_in = (last_mod && mlp_in_on_cross_out) ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
+        gemm<NP, TK_SQUARE>(c, KC_GEMM_CROSS_OUT, e == 0 ? ao : m->ao2, J, w.wo_cross[e], J, BT, D, J, ec, 0, &pf_in);
       }
     }
     // (iii) MLP block (network.py:241-256)

@@ -69,6 +69,16 @@ sixth)   # touch-ahead of the NEXT cross-attention launch's entry stages: bitwis
   timeout 400 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_touch_next_ab.json 'kv_touch_ahead=0' 'kv_touch_ahead=102' 'kv_touch_ahead=2' 'kv_touch_ahead=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_next_ab.log
   timeout 400 python tools/ab/knob_ab.py --rounds 3 --tokens 300 --tokens 900 --json $OUT/${TAG}_touch_next_ab2.json 'kv_touch_ahead=0' 'kv_touch_ahead=102' 'kv_touch_ahead=2' 2>&1 | grep -v Warning | tee $OUT/${TAG}_touch_next_ab2.log
   ;;
+seventh) # 128-row cross-attention blocks at batch: parity, then this round's record binary (r05y) against the new one
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "batched_songs or base_size or exact_launch" > $OUT/${TAG}_qb4_tests.log 2>&1; tail -4 $OUT/${TAG}_qb4_tests.log
+  for nb in 8 4 16; do
+    for r in 1 2; do
+      for L in "MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r05y.so" "X=0"; do
+        env $L timeout 300 python bench.py --batch $nb --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[batch $nb $L]', d['value'], d['ms_per_step'])"
+      done
+    done
+  done 2>&1 | tee $OUT/${TAG}_qb4_ab.log
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
