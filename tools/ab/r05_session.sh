@@ -79,6 +79,9 @@ seventh) # 128-row cross-attention blocks at batch: parity, then this round's re
     done
   done 2>&1 | tee $OUT/${TAG}_qb4_ab.log
   ;;
+eighth)  # one song: split 8 now runs on 128-row blocks (192 blocks whose whole key range fits the ring) -- against the default
+  timeout 600 python tools/ab/knob_ab.py --rounds 4 --tokens 300 --tokens 900 --tokens 1300 --tokens 1536 --json $OUT/${TAG}_split8_qb4.json '' 'cross_key_split=8' 'cross_key_split=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_split8_qb4.log
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "FAILED|ERROR" $OUT/${TAG}_gpu_tests.log | head -20
