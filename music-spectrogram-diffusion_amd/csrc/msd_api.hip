@@ -561,7 +561,9 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   // 2 songs +1.1 %, 4 songs +3.5 %, 8 songs +3.1 % -- batched launches are bandwidth-bound and the touches only add
   // requests -- so the library turns it on for one song only, whatever msd_config.kv_touch_ahead asks for beyond that.
   p.touch_ahead = (kc == KC_ATTN_CROSS && segs == 1) ? c.m->kv_touch_ahead : 0;
-  p.allow_qb4 = kc == KC_ATTN_CROSS;   // (batched cross-attention: 128-row blocks, attention.h attention_query_blocks)
+  // 128-row blocks (attention.h attention_query_blocks) for the DECODER's attentions at batch: the cross-attention, and
+  // the self-attention when its caller has taken the weight target off the launch (an empty, non-null prefetch)
+  p.allow_qb4 = kc == KC_ATTN_CROSS || (kc == KC_ATTN_SELF && pf != nullptr && pf->n == 0);
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
@@ -1021,11 +1023,16 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
       gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, Ms, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
+    // (a self-attention launch on 128-row blocks -- more than one round of 64-row blocks, i.e. from 6 songs per handle --
+    // has no prefetch wave: its weight target rides on the out-projection below instead)
+    const bool self_qb4 = attention_query_blocks(m->H * (T / 64) * Ps * batch, T, NP) == 4;
+    const WeightPrefetch pf_self = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
     {
-      WeightPrefetch pf = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
+      const WeightPrefetch none;
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
-                    (size_t)J * T, ao, J, nkeys_self, T, m->H, Ps * batch, 1, 0, &pf);
+                    (size_t)J * T, ao, J, nkeys_self, T, m->H, Ps * batch, 1, 0, self_qb4 ? &none : &pf_self);
     }
+    const WeightPrefetch* pf_out = self_qb4 ? &pf_self : nullptr;
     // out-projection + residual; produces y for the cross-attention norm (conditional rows:
     // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
     EpiResidualNorm<NP> er;
@@ -1039,9 +1046,9 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
       ed.x = x; ed.ldx = D; ed.y[0] = y.p[0]; ed.y[1] = y.p[NP - 1]; ed.ssq = ssq; ed.tiles = tiles; ed.step_ptr = m->d_step;
       ed.g_lo = er.g_lo; ed.g_lo_stride = er.g_lo_stride; ed.g_hi = er.g_hi; ed.g_hi_stride = er.g_hi_stride;
       ed.split_row = 0; ed.dup_rows = BT;
-      gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, BT, D, J, ed);
+      gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, BT, D, J, ed, 0, pf_out);
     } else
-    gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er);
+    gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er, 0, pf_out);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
     if (cond0) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
