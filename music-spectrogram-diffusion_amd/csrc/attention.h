@@ -101,12 +101,6 @@ __host__ __device__ inline int attention_query_blocks(int blocks64, int q_rows_p
   return 2;
 }
 
-// QB = 2: 64 query rows per block share each K/V stage (cross-attention: K/V traffic halves);
-// QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
-// (decoder self-attention at B = 1: 12 heads x 4 x 2 passes = 96 blocks of 64 rows).
-// QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
-// O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
-// (K, V) always keeps both planes (DESIGN.md 3: dropping those costs 20 - 50x the error).  0 = all three products.
 // K / V^T touch-ahead (round 5), run by the block's PREFETCH WAVE.  The cached cross-attention K / V^T are HBM-cold at every
 // step and the ring holds NS = 2 stages of 64 KiB: a block waits one full HBM latency (3.5 us: the
 // "issued -> stage 0 landed" of the phase stamps) for its first stage and AGAIN for every stage it issues later -- its
@@ -176,6 +170,13 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
   }
 }
 
+// QB query blocks of 32 rows per workgroup (attention_query_blocks above): QB = 2: 64 query rows share each K/V stage;
+// QB = 4: 128 rows, 16 waves, no prefetch wave (batched decoder attentions);
+// QB = 1: 32 query rows, twice the blocks -- for launches that would otherwise leave most CUs idle
+// (decoder self-attention at B = 1: 12 heads x 4 x 2 passes = 96 blocks of 64 rows).
+// QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
+// O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
+// (K, V) always keeps both planes (DESIGN.md 3: dropping those costs 20 - 50x the error).  0 = all three products.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
   static_assert(QB < 4 || PF == kPfNone, "16 compute waves fill the workgroup: no prefetch wave");
