@@ -190,13 +190,29 @@ int fail(const msd_model* m, int code, const char* fmt, ...) {
                   "msd_api.hip", __LINE__); /* not __FILE__: no checkout path in the binary */ \
   } while (0)
 
+// Synchronous copies and fills of a handle go through the handle's own NON-BLOCKING stream, never through the legacy
+// (NULL) stream: a legacy-stream operation synchronises with every blocking stream of the device and FAILS while another
+// thread captures a graph on one ("operation would make the legacy stream depend on a capturing blocking stream") --
+// a second handle that loads its weights, or encodes, while the first one captures its step graph (round 5: found by
+// tools/ab/multi_handle.py).  Handles on one device may now be created, loaded and run from different threads.
+hipError_t copy_sync(const msd_model* m, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (!m || !m->own_stream) return hipMemcpy(dst, src, bytes, kind);
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, m->own_stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(m->own_stream);
+}
+hipError_t fill_sync(const msd_model* m, void* dst, int value, size_t bytes) {
+  if (!m || !m->own_stream) return hipMemset(dst, value, bytes);
+  const hipError_t e = hipMemsetAsync(dst, value, bytes, m->own_stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(m->own_stream);
+}
+
 template <class Tp>
 int dalloc(msd_model* m, Tp** out, size_t count, bool zero = true) {
   void* p = nullptr;
   size_t bytes = count * sizeof(Tp);
   if (bytes == 0) bytes = 16;
   HIP_TRY(m, hipMalloc(&p, bytes));
-  if (zero) HIP_TRY(m, hipMemset(p, 0, bytes));
+  if (zero) HIP_TRY(m, fill_sync(m, p, 0, bytes));
   m->allocs.push_back(p);
   *out = static_cast<Tp*>(p);
   return MSD_OK;
@@ -1204,6 +1220,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->struct_size != (int32_t)sizeof(msd_config)) return MSD_ERR_INVALID_ARGUMENT;
   msd_model* m = new msd_model();
   m->cfg = *cfg;
+  (void)hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);   // first: every fill / copy below goes through it (copy_sync)
   auto bad = [&](const char* why) {
     // keep the handle alive so the caller can read the message
     m->err = why;
@@ -1319,7 +1336,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->h_nkeys_cross.assign((size_t)m->n_cross * m->Bmax, 0);
   {
     std::vector<int> nk((size_t)m->passes * m->Bmax, T);
-    HIP_TRY(m, hipMemcpy(m->d_nkeys_self, nk.data(), nk.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(m, copy_sync(m, m->d_nkeys_self, nk.data(), nk.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   TRY(palloc(m, &m->kc, (size_t)m->Ld * m->Bmax * m->S_pad * J));
   TRY(palloc(m, &m->vtc, (size_t)m->Ld * m->Bmax * m->S_pad * J));
@@ -1341,7 +1358,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
 #undef TRY
   HIP_TRY(m, hipEventCreate(&m->prof.e0));
   HIP_TRY(m, hipEventCreate(&m->prof.e1));
-  HIP_TRY(m, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  if (!m->own_stream) return fail(m, MSD_ERR_HIP, "hipStreamCreateWithFlags failed");
   return MSD_OK;
 }
 
@@ -1380,7 +1397,7 @@ int msd_set_weight(msd_model* m, const char* name, const float* data, const int6
   if (!w.dev)
     return fail(m, MSD_ERR_BAD_STATE, "weight '%s': msd_finalize_weights has run and freed its staging copy (weights are "
                 "loaded once per handle; create a new model)", name);
-  HIP_TRY(m, hipMemcpy(w.dev, data, (size_t)w.numel() * sizeof(float), hipMemcpyDefault));
+  HIP_TRY(m, copy_sync(m, w.dev, data, (size_t)w.numel() * sizeof(float), hipMemcpyDefault));
   w.set = true;
   m->finalized = false;
   return MSD_OK;
@@ -1452,7 +1469,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
   HIP_TRY(m, hipStreamSynchronize(s));
   {  // half planes hold kWScale * w: |w| must stay below 65504 / kWScale (common.h)
     float top = 0.f;
-    HIP_TRY(m, hipMemcpy(&top, m->d_absmax, sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(m, copy_sync(m, &top, m->d_absmax, sizeof(float), hipMemcpyDeviceToHost));
     if (!(top < kPlaneMax / kWScale))
       return fail(m, MSD_ERR_UNSUPPORTED,
                   "a projection weight has magnitude %g: the %s of this build hold |w| < %g (the bfloat16-plane build, "
@@ -1488,10 +1505,10 @@ int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_
   hipStream_t s = static_cast<hipStream_t>(stream);
   // tokens / mask may live on either side: stage them on the host (a few KiB)
   std::vector<int32_t> tok_h((size_t)batch * m->L), mask_h;
-  HIP_TRY(m, hipMemcpy(tok_h.data(), tokens, tok_h.size() * sizeof(int32_t), hipMemcpyDefault));
+  HIP_TRY(m, copy_sync(m, tok_h.data(), tokens, tok_h.size() * sizeof(int32_t), hipMemcpyDefault));
   if (m->cfg.has_context) {
     mask_h.resize((size_t)batch * m->C);
-    HIP_TRY(m, hipMemcpy(mask_h.data(), ctx_mask, mask_h.size() * sizeof(int32_t), hipMemcpyDefault));
+    HIP_TRY(m, copy_sync(m, mask_h.data(), ctx_mask, mask_h.size() * sizeof(int32_t), hipMemcpyDefault));
   }
   for (int32_t t : tok_h)
     if (t < 0 || t >= m->cfg.vocab_size) return fail(m, MSD_ERR_INVALID_ARGUMENT, "token id %d outside [0, %d)", t, m->cfg.vocab_size);
@@ -1999,7 +2016,6 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     (void)hipMemcpyAsync(film + D, film_bias_dev, D * sizeof(float), hipMemcpyDeviceToDevice, s);
   }
   hipError_t e = hipSuccess;
-  int* sk_err = nullptr;
   if (folded) {
     hipLaunchKernelGGL(build_g_kernel, dim3((D + 255) / 256), dim3(256), 0, s, film, gamma_dev, g, 1, 1, 0, D);
     GemmF32Params bp;   // bias . W2 : one row
@@ -2033,10 +2049,6 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
   }
   if (e != hipSuccess || hipGetLastError() != hipSuccess) return MSD_ERR_HIP;
   if (const int rc = fl.finish(s)) return rc;
-  if (sk_err) {   // split-K: barrier timeouts / block groups spread over several XCDs
-    int bad = 0;
-    if (hipMemcpy(&bad, sk_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || bad) return MSD_ERR_HIP;
-  }
   return MSD_OK;
 }
 

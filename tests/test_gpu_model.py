@@ -596,3 +596,42 @@ def test_staging_copies_of_packed_weights_are_freed():
     del model
   assert np.array_equal(np.asarray(outs[True]), np.asarray(outs[False]))
   assert used[True] - used[False] > 0.6 * matrices, (used, matrices)   # (the allocator returns whole 2 MiB blocks: measured 0.77)
+
+
+def test_two_handles_from_two_threads_on_one_device():
+  """Handles are independent: two threads may create, load and run one each on the SAME device at the same time
+  (include/msd_amd.h "Threading").  Round 5: the library's synchronous copies / fills go through the handle's own
+  non-blocking stream -- through the legacy stream, a second handle that loaded its weights while the first captured its
+  step graph failed both ("operation would make the legacy stream depend on a capturing blocking stream").  Results
+  equal the same work done one after the other, bit for bit."""
+  import threading
+  spec = msd_amd.config.preset('tiny_context', num_steps=16)
+  params = [msd_amd.synthetic.init_params(spec, 20 + i, norm_scale_jitter=0.1) for i in range(2)]
+  batches = [helpers.make_batch(spec, batch=1, seed=30 + i, ctx_mask='ones') for i in range(2)]
+
+  def run(i, out):
+    model = msd_amd.InferenceModel(params[i], spec)
+    a, _ = model.predict(batches[i], seed=i, segment=0)
+    b, _ = model.predict(batches[i], seed=i, segment=1)
+    out[i] = (np.asarray(a), np.asarray(b))
+
+  want = {}
+  for i in range(2):
+    run(i, want)
+  for _ in range(3):                       # a few times: the race is a matter of timing
+    got, errs = {}, []
+
+    def guarded(i):
+      try:
+        run(i, got)
+      except Exception as e:               # noqa: BLE001 -- reported below, from the main thread
+        errs.append(repr(e))
+
+    threads = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
+    for t in threads:
+      t.start()
+    for t in threads:
+      t.join()
+    assert not errs, errs
+    for i in range(2):
+      assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1])
