@@ -18,7 +18,9 @@
  * Conventions
  *   - plain C types only; every function returns an msd_status (0 = ok) and never
  *     throws; msd_last_error() gives the message for the last failure on a handle.
- *   - one handle <-> one device <-> one caller thread at a time (not re-entrant).
+ *   - one handle <-> one device <-> one caller thread at a time (not re-entrant).  Handles are independent of each
+ *     other: several may be created, loaded and run concurrently from different threads, also on ONE device (the
+ *     library's own synchronous copies use a non-blocking stream of the handle, never the legacy stream).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
  *     device work is enqueued on it; calls return without synchronising unless
  *     stated.
