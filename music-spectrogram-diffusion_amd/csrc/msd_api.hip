@@ -1457,7 +1457,7 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     // base_with_context moves 396 MB of packed decoder weights + 170 MB of cached cross K/V per step, so every
     // launch used to start on HBM-cold operands (1.172 -> 1.09 ms/step with the prefetch); the `small` preset moves
     // 143 MB, its weights simply stay cached from one step to the next and the touches are pure overhead
-    // (489 -> 501 ms per segment: profiles/r02_prefetch_ab.log).  MSD_PREFETCH=0/1 overrides.
+    // (489 -> 501 ms per segment: profiles/r02_prefetch_ab.log).  msd_config.weight_prefetch overrides.
     const size_t planes = (size_t)m->NP * sizeof(h16_t);
     const size_t per_layer = ((size_t)3 * J * D + (size_t)D * J + (size_t)m->n_cross * 2 * ((size_t)J * D) +
                               (size_t)2 * m->F * D + (size_t)D * m->F) * planes;
@@ -1620,7 +1620,7 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
                      (int)n, m->cfg.feature_min, m->cfg.feature_max);
   HIP_TRY(m, hipGetLastError());
   // The call ends with ONE stream synchronisation (tens of microseconds against a ~1 s segment): behind it the
-  // half-plane range flag and the chain kernels' barrier flag are read, so that a bad run fails THIS call.
+  // half-plane range flag is read, so that a bad run fails THIS call.
   return check_range(m, s, "msd_sample");
 }
 
@@ -2027,7 +2027,7 @@ int msd_op_residual_norm_gemm(int folded, const float* x_in_dev, const float* a_
     GemmParams p1 = gp<2>(a, K, w1, K, M, D, K);
     p1.xcd_rows = 2; p1.xcd_walk_n = 1;
     fl.arm(p1);
-    if (folded == 2) {   // the producer as the 4-way split-K launch of the experiments build (gemm_h16_splitk_kernel)
+    if (folded == 2) {   // (was: the split-K producer of the frozen experiments build, tools/ubench/exp -- not in the product)
       return MSD_ERR_UNSUPPORTED;
     } else if (folded == 3) {   // the producer on 32 x 48 tiles (one partial sum per row and tile + zeroed spare slots)
       if (D % kWide48 || M % 32) return MSD_ERR_INVALID_ARGUMENT;
