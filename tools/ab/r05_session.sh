@@ -82,11 +82,11 @@ seventh) # 128-row cross-attention blocks at batch: parity, then this round's re
 eighth)  # one song: split 8 now runs on 128-row blocks (192 blocks whose whole key range fits the ring) -- against the default
   timeout 600 python tools/ab/knob_ab.py --rounds 4 --tokens 300 --tokens 900 --tokens 1300 --tokens 1536 --json $OUT/${TAG}_split8_qb4.json '' 'cross_key_split=8' 'cross_key_split=4' 2>&1 | grep -v Warning | tee $OUT/${TAG}_split8_qb4.log
   ;;
-ninth)   # 128-row blocks for the batched decoder SELF-attention too: parity, then the r05z binary against the new one
+ninth)   # 128-row blocks for the batched decoder SELF-attention too: parity, then the r05x binary (one commit earlier) against the new one
   timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "batched_songs or base_size or exact_launch" > $OUT/${TAG}_qb4s_tests.log 2>&1; tail -4 $OUT/${TAG}_qb4s_tests.log
   for nb in 8 16; do
     for r in 1 2; do
-      for L in "MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r05z.so" "X=0"; do
+      for L in "MSD_AMD_LIB=$ROOT/tools/ab/libs/libmsd_amd_r05x.so" "X=0"; do
         env $L timeout 300 python bench.py --batch $nb --steps 2 --warmup 1 --no-cpu-baseline --batched-songs 0 --small-segments 0 --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[batch $nb $L]', d['value'], d['ms_per_step'])"
       done
     done
