@@ -132,3 +132,40 @@ def test_roofline_classifies_by_step_instantiation_not_by_substring():
   assert busy == 9437184.0                          # = 3 x 3.2212 GFLOP / 16384 FLOP per MFMA x 16 cycles
   util = busy / (1024 * 14.905e-6 * 2.4e9)
   assert abs(util - 0.258) < 1e-3
+
+
+def test_kernel_stats_classes_of_a_committed_trace():
+  """bench.py's own rocprofv3 leg (self_profile) reads a kernel_stats table the way tools/make_roofline.py does: the
+  step graph's instantiations only, one class each, launches per step from the sampler's call count; the per-class us
+  times launches add up to the trace's kernel time per step."""
+  stats = os.path.join(ROOT, 'profiles', 'r05z_bench_kernel_stats.csv')
+  classes, steps = bench.kernel_stats_classes(stats)
+  assert steps == 2001
+  assert classes['gemm_mlp_in_geglu']['launches_per_step'] == 12.0 and 12.0 < classes['gemm_mlp_in_geglu']['avg_us'] < 16.0
+  assert classes['gemm_qkv']['launches_per_step'] == 11.0 and classes['gemm_qkv_l0']['launches_per_step'] == 1.0
+  assert sum(e['launches_per_step'] for e in classes.values()) == 111.0
+  sp = {'per_class': classes, 's_valid_keys': 1356.0, 'child_sample_ms_per_segment': 960.0,
+        'sum_kernel_us_per_step': sum(e['avg_us'] * e['calls'] for e in classes.values()) / steps}
+  spec = msd_amd.config.preset('base_with_context')
+  dom, table, whole, flops, abytes = bench.roofline_from_self_profile(spec, sp, 2, 2, graph_step_ms=0.96)
+  assert dom == 'gemm_mlp_in_geglu' and abs(table[dom]['frac'] - 0.0946) < 2e-3        # VERDICT r05's recomputation
+  assert 0.9 < whole['kernel_time_over_child_step'] <= 1.0 and 100 < whole['algorithmic_gflop'] < 125
+  assert abs(whole['sum_kernel_us'] - 956.6) < 1.0 and whole['launches'] == 111.0
+
+
+def test_classify_a_model_without_cross_attention():
+  """`small`: no cross block, and the residual template's one instantiation serves attention-out AND MLP-out."""
+  names = {'gemm_h16_dma_kernel<2, 64, 64, 3, EpiQKV<2>, 0>', 'gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, false>, 0>',
+           'gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, true>, 0>', 'gemm_h16_dma_kernel<2, 64, 64, 3, EpiGeglu<2>, 0>',
+           'attention_kernel<2, 2, 1, 0, 0>', 'final_proj_f32_kernel<1>', 'sampler_step_kernel<0>',
+           'gemm_h16_dma_kernel<2, 32, 32, 4, EpiInProj<2>, 0>'}
+  got = {n: bench.classify_kernel('void msd::' + n + '(msd::GemmParams)', names) for n in names}
+  assert got['gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, false>, 0>'] == 'gemm_attn_out+gemm_mlp_out'
+  assert got['gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, true>, 0>'] == 'gemm_attn_out_l0'
+  assert got['gemm_h16_dma_kernel<2, 64, 64, 3, EpiQKV<2>, 0>'] == 'gemm_qkv' and None not in got.values()
+  flops, _ = bench.class_work(msd_amd.config.preset('small'), 1100.0, 2)
+  assert flops['gemm_attn_out'] < flops['gemm_attn_out+gemm_mlp_out'] < flops['gemm_mlp_out']
+
+
+def test_watchdog_exit_code_is_a_failure():
+  assert bench.Watchdog.EXIT_CODE != 0

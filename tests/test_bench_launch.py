@@ -70,6 +70,9 @@ def test_a_hung_handoff_leg_still_prints_the_replicas_line():
                 timeout=120)
   lines = json_lines(p.stdout)
   assert len(lines) == 1, (p.stdout, p.stderr[-2000:])
+  # ... and the plain command's exit code says that the run did NOT end cleanly (round 6: the watchdog used to leave
+  # with 0 -- a hung hand-off looked like a clean run to whoever only reads the exit code)
+  assert p.returncode != 0, p.returncode
   d = lines[0]
   assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['mode'] == 'replicas'
   assert d['handoff']['ok'] is False and 'did not finish' in d['handoff']['error']

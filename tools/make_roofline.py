@@ -28,64 +28,11 @@ import msd_amd  # noqa: E402
 
 CLOCK_GHZ = 2.4      # MI355X peak engine clock (MI355X_MICROARCH.md); SQ cycle counters tick at the engine clock
 SIMDS = 256 * 4
-# (substring of the demangled kernel name, class) -- first match wins.  Round 3 renamed the 16-bit-plane kernels
-# (gemm_bf16_* -> gemm_h16_*, EpiStoreBf16 -> EpiStoreH16) and added the dual launch of the hoisted query projection;
-# the round-2 names stay so that the committed r02 traces still classify.
-CLASS = [
-    ('gemm_h16_dual_kernel', 'gemm_attn_out+cross_q'),      # self-attention output projection + hoisted cross-attention q
-    ('gemm_h16_splitk_kernel', 'gemm_mlp_out'),
-    ('EpiGeglu', 'gemm_mlp_in_geglu'), ('EpiQKV', 'gemm_qkv'),
-    ('64, 32, 4, msd::EpiResidualNorm', 'gemm_mlp_out'), ('64, 32, 4, EpiResidualNorm', 'gemm_mlp_out'),
-    ('32, 32, 4, msd::EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'), ('32, 32, 4, EpiResidualNorm', 'gemm_attn_out+gemm_cross_out'),
-    ('32, 32, 4, msd::EpiStoreBf16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreBf16', 'gemm_cross_q'),
-    ('32, 32, 4, msd::EpiStoreH16', 'gemm_cross_q'), ('32, 32, 4, EpiStoreH16', 'gemm_cross_q'),
-    ('attention_merge_kernel', 'attn_cross_merge'),
-    ('attention_kernel<2, 2, 1', 'attn_self'), ('attention_kernel<2, 2, 2', 'attn_cross'),
-    ('final_proj_f32_kernel', 'final_proj_f32'), ('EpiInProj', 'in_proj_f32'), ('sampler_step_kernel', 'sampler_step'),
-]
-
-
-def normalise(name):
-  """kernel name as tools/pmc_summary.py prints it: no return type, no namespace, no argument list"""
-  return name.split('(')[0].replace('void msd::', '').replace('msd::', '').strip()
-
-
-def classify(name, step_kernels=None):
-  """class of a kernel INSTANTIATION.  `step_kernels`: the normalised names of the instantiations the DDPM-step graph
-  replays; anything else (the encoders run the same templates at other shapes, without the weight prefetch and with
-  all attention planes: `EpiGeglu<2>, 0`, `attention_kernel<2, 2, 2, 0, 0>`, ...) is NOT part of a class -- round 3
-  classified by substring only and averaged the encoder's M = 2048 launches into the decoder's counters
-  (VERDICT r03 weak #3: MLP-in mfma_util 0.294 instead of 0.258, traffic 45.7 instead of 42.4 MB)."""
-  if step_kernels is not None and normalise(name) not in step_kernels:
-    return None
-  # round 4: the MLP output projection moved to the 32 x 48 tile and the self-attention output projection to the 64 x 32
-  # one, so in a trace that holds a 32 x 48 instantiation the 64 x 32 / 32 x 32 residual templates are attention-out /
-  # cross-out (one class each); older traces keep round 3's meaning (the table below)
-  if step_kernels is not None and any('32, 48, 4' in k for k in step_kernels) and 'EpiResidualNorm' in name:
-    # round 5: layer 0's self-attention block runs on one CFG pass's rows (S5): its out-projection is the duplicating
-    # epilogue EpiResidualNorm<2, true> on 32 x 32 tiles (M = 256) -- a class of its own, one launch per step
-    if 'EpiResidualNorm<2, true>' in name:
-      return 'gemm_attn_out_l0'
-    for sub, cls in (('32, 48, 4', 'gemm_mlp_out'), ('64, 32, 4', 'gemm_attn_out'), ('32, 32, 4', 'gemm_cross_out')):
-      if sub in name:
-        return cls
-  if step_kernels is not None and 'EpiQKV' in name and '64, 64, 3' in name and any('64, 96, 3' in k and 'EpiQKV' in k for k in step_kernels):
-    return 'gemm_qkv_l0'      # layer 0's QKV projection on M = 256 rows (S5): 64 x 64 tiles, one launch per step
-  for sub, cls in CLASS:
-    if sub in name:
-      return cls
-  return None
-
-
-def step_kernel_names(stats_csv):
-  """The instantiations that belong to the DDPM step: the sampler runs exactly once per step, so every kernel of the
-  step graph has at least that many calls in a trace, while an encoder or load-time launch has a few dozen."""
-  rows = list(csv.DictReader(open(stats_csv)))
-  per_step = [int(r['Calls']) for r in rows if 'sampler_step_kernel' in r['Name']]
-  if not per_step:
-    return None
-  floor = max(per_step) // 2
-  return {normalise(r['Name']) for r in rows if int(r['Calls']) >= floor}
+# kernel name -> class: ONE table for this tool and for bench.py's own rocprofv3 leg (bench.py KERNEL_CLASSES)
+CLASS = bench.KERNEL_CLASSES
+normalise = bench.normalise_kernel
+classify = bench.classify_kernel
+step_kernel_names = bench.step_kernel_names
 
 
 def main():
