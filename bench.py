@@ -589,6 +589,7 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
   import torch
   from msd_amd import sharding
   try:
+    sharding.warm_up(None, device)   # communicators / peer connections exist before anything here is timed
     buf = torch.empty(sharding.HEADER + int(np.prod(shape)), dtype=torch.float32, device=device)
     _sync(device)
     dist.barrier()
@@ -614,6 +615,7 @@ def handoff_check(dist, rank, world, device, shape=(1, 256, 128), rounds=20):
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return {'ok': bool(flag.item() == 1.0), 'message_bytes': int(np.prod(shape)) * 4, 'hops': world - 1,
+            'warm_up': sharding.last_warm_up,   # seconds in the group's first collective / first point-to-point chain, both untimed
             'us_per_hop': round(float(tt.item()) / rounds / max(world - 1, 1) * 1e6, 1),
             'note': 'header-checked message of sharding.chained_predict: isend / recv of the device tensor (RCCL point-to-point, one communicator per peer pair); one message per chunk boundary in --mode chained'}
   except Exception as e:  # never let the probe take the benchmark down

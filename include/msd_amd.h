@@ -20,7 +20,10 @@
  *     throws; msd_last_error() gives the message for the last failure on a handle.
  *   - one handle <-> one device <-> one caller thread at a time (not re-entrant).  Handles are independent of each
  *     other: several may be created, loaded and run concurrently from different threads, also on ONE device (the
- *     library's own synchronous copies use a non-blocking stream of the handle, never the legacy stream).
+ *     library's own synchronous copies use a non-blocking stream of the handle, never the legacy stream).  This
+ *     covers every msd_* entry point that takes a handle; the stand-alone msd_op_* building blocks (unit-test entry
+ *     points: they allocate, clear and copy scratch through the legacy stream) are NOT part of that guarantee -- do
+ *     not call them while another thread captures or runs a model.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
  *     device work is enqueued on it; calls return without synchronising unless
  *     stated.
@@ -169,7 +172,11 @@ typedef struct msd_config {
   int32_t kv_touch_ahead;         /* the cross-attention launches' prefetch wave touches the cached K / V^T lines this
                                      many 128-key ring stages ahead of their LDS-DMA (they are HBM-cold at every
                                      step): 0 = the library's choice (2, with one song per handle; batched launches
-                                     are bandwidth-bound and never touch), -1 = off, 1 .. 16 */
+                                     are bandwidth-bound and never touch), -1 = off, 1 .. 16.  The touches ride on the
+                                     launch's weight-prefetch wave: a cross-attention launch WITHOUT a weight target
+                                     (weight_prefetch off -- the library's choice for models whose step fits the 256 MB
+                                     cache, e.g. `small` / tiny presets -- or a module other than a layer's last) never
+                                     touches, whatever this field says */
 } msd_config;
 
 const char* msd_version(void);
@@ -185,8 +192,10 @@ const char* msd_last_error(const msd_model* m);
 /* Parameter tree.  Names are the Flax names of the reference modules, '/'-joined
  * (e.g. "decoder/layers_3/FiLMLayer_0/DenseGeneral_0/kernel"); shapes as stored
  * by the reference ([in, out] kernels, layers.py:430-431).  `data` may be host or
- * device memory (hipMemcpyDefault).  Replaces the params pytree handed to
- * predict_fn (inference.py:197-203). */
+ * device memory (hipMemcpyDefault; the copy runs on the handle's own stream and the call has no stream argument, so
+ * a DEVICE-side `data` must be complete -- its producer stream synchronised -- before the call).  Weights are loaded
+ * ONCE per handle: after msd_finalize_weights every msd_set_weight returns MSD_ERR_BAD_STATE.  Replaces the params
+ * pytree handed to predict_fn (inference.py:197-203). */
 int msd_num_weights(const msd_model* m);
 int msd_weight_info(const msd_model* m, int index, const char** name, int64_t shape[2], int* ndim);
 int msd_set_weight(msd_model* m, const char* name, const float* data,
@@ -200,7 +209,9 @@ int msd_finalize_weights(msd_model* m, void* stream);
  * models.py:361-363) once and caches the decoder's cross-attention K/V.
  *   tokens   int32 [batch, L]        (host or device)
  *   ctx      float [batch, C, n]     mel units (device), NULL without context
- *   ctx_mask int32 [batch, C]        (host or device), NULL without context   */
+ *   ctx_mask int32 [batch, C]        (host or device), NULL without context
+ * Synchronises `stream` at entry (device-side tokens / ctx_mask written on it are staged through the host) and before
+ * it returns (half-plane range flag, like msd_sample). */
 int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_dev,
                const int32_t* ctx_mask, void* stream);
 
@@ -209,7 +220,11 @@ int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_
  * activations left the plane range fails THIS call with MSD_ERR_RANGE instead of handing back a wrong spectrogram.
  *   init_z_dev float [batch,T,n] or NULL  -> generated (Philox, see msd_fill_normal)
  *   noise_dev  float [N,batch,T,n] or NULL -> generated; noise_dev[i] is the draw
- *              used at scan index i (diffusion_utils.py:389-390)
+ *              used at scan index i (diffusion_utils.py:389-390).  NULL: the sampler kernel draws step i's noise
+ *              itself (sub-sequence 1 + i of msd_fill_normal's generator: no [N,batch,T,n] buffer exists; the
+ *              values are those msd_fill_normal(seed, stream_id, 1 + i, ...) writes, bit for bit)
+ *   stream     NULL = the legacy stream: the call waits for it (hipStreamSynchronize(NULL)) and runs on the handle's
+ *              own stream (the legacy stream cannot be captured); other handles' streams are not waited for
  *   seed/stream_id key the generator when a pointer is NULL (stream_id = segment)
  *   out_dev    float [batch,T,n] mel units                                    */
 int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id,

@@ -82,6 +82,54 @@ __global__ void __launch_bounds__(256) rmsnorm_film_kernel(NormParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller standard normals (documented generator shared with
+// oracle/philox.py).  key = (seed_lo, seed_hi); counter = (block, subseq,
+// stream_lo, stream_hi); element e = 4*block + j, j in 0..3;
+//   u = ((x >> 8) + 0.5) * 2^-24 ; (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+// The four normals of counter block `blk` of sub-sequence `subseq`: ONE function for the fill kernel below and for the
+// sampler's own draw (sampler_step_kernel with no noise buffer), so that both write the same bits.
+__device__ __forceinline__ void philox_normal4(uint32_t blk, uint32_t subseq, uint32_t seed_lo, uint32_t seed_hi,
+                                               uint32_t stream_lo, uint32_t stream_hi, float (&z)[4]) {
+  uint32_t c[4] = {blk, subseq, stream_lo, stream_hi};
+  philox4x32_10(c, seed_lo, seed_hi);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u0 = ((float)(c[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u1 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float rad = sqrtf(-2.0f * logf(u0));
+    const float ang = 6.283185307179586f * u1;
+    z[2 * h] = rad * cosf(ang);
+    z[2 * h + 1] = rad * sinf(ang);
+  }
+}
+
+// grid.y = number of consecutive sub-sequences; row y gets subseq0 + y, offset y * n
+__global__ void philox_normal_kernel(float* out, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                                     uint32_t stream_lo, uint32_t stream_hi, uint32_t subseq0) {
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk * 4 >= n) return;
+  out += (int64_t)blockIdx.y * n;
+  float z[4];
+  philox_normal4((uint32_t)blk, subseq0 + blockIdx.y, seed_lo, seed_hi, stream_lo, stream_hi, z);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (blk * 4 + j < n) out[blk * 4 + j] = z[j];
+}
+
+// ---------------------------------------------------------------------------
 // Fused sampler update = everything in eval_step.body after the decoder calls
 // (diffusion_utils.py:416-452): CFG combine, x0-from-eps, clip, posterior mean,
 // + std * noise (DDPM, diffusion_utils.py:120-163,382-395) or the DDIM update
@@ -101,7 +149,11 @@ enum { kOutEps = 0, kOutX0 = 1, kOutV = 2 };   // = msd_model_output
 struct SamplerParams {
   const float* eps;     // [passes][n] decoder outputs (pass 0 = conditional)
   float* z;             // [n] in/out
-  const float* const* noise_slot;  // device slot holding the [N][n] per-step draws pointer
+  const float* const* noise_slot;  // device slot holding the [N][n] per-step draws pointer; a NULL pointer there = draw here
+  const uint32_t* rng_key = nullptr;   // device words {seed_lo, seed_hi, stream_lo, stream_hi} of the in-kernel draw (round 6):
+                                       // step i's noise = sub-sequence 1 + i of the caller's Philox stream, element block =
+                                       // this thread -- exactly the row philox_normal_kernel used to write for it (the
+                                       // [N][n] buffer: 131 MB x songs at base, a hipMalloc inside msd_sample)
   const float* coef;    // [N][kCoefCount]
   int* step_ptr;        // scan index i (device); see step_from_slot1
   int step_from_slot1 = 0;
@@ -179,7 +231,17 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerParams p) {
     f32x4 cr[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) cr[k] = reinterpret_cast<const f32x4*>(p.coef + (size_t)i * kCoefCount)[k];
-    if (!p.ddim && i != 0) nz = *reinterpret_cast<const f32x4*>(*p.noise_slot + (size_t)i * p.n + idx);
+    if (!p.ddim && i != 0) {
+      const float* const noise = *p.noise_slot;   // (wave-uniform: one branch)
+      if (noise != nullptr) {
+        nz = *reinterpret_cast<const f32x4*>(noise + (size_t)i * p.n + idx);
+      } else {   // no buffer: this thread's four draws of sub-sequence 1 + i (idx / 4 = the counter block)
+        const uint32_t k0 = p.rng_key[0], k1 = p.rng_key[1], s0 = p.rng_key[2], s1 = p.rng_key[3];
+        float d[4];
+        philox_normal4((uint32_t)(idx >> 2), 1u + (uint32_t)i, k0, k1, s0, s1, d);
+        nz = f32x4{d[0], d[1], d[2], d[3]};
+      }
+    }
     float c[kCoefCount];
 #pragma unroll
     for (int k = 0; k < kCoefCount; ++k) c[k] = cr[k >> 2][k & 3];
@@ -293,47 +355,6 @@ __global__ void gather_rows_kernel(const float* src, const int* idx, int n_valid
   const int r = blockIdx.x;
   for (int c = threadIdx.x; c < D; c += blockDim.x)
     dst[(size_t)r * D + c] = (r < n_valid) ? src[(size_t)idx[r] * D + c] : 0.f;
-}
-
-// ---------------------------------------------------------------------------
-// Philox4x32-10 + Box-Muller standard normals (documented generator shared with
-// oracle/philox.py).  key = (seed_lo, seed_hi); counter = (block, subseq,
-// stream_lo, stream_hi); element e = 4*block + j, j in 0..3;
-//   u = ((x >> 8) + 0.5) * 2^-24 ; (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += W0; k1 += W1;
-  }
-}
-
-// grid.y = number of consecutive sub-sequences; row y gets subseq0 + y, offset y * n
-__global__ void philox_normal_kernel(float* out, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
-                                     uint32_t stream_lo, uint32_t stream_hi, uint32_t subseq0) {
-  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blk * 4 >= n) return;
-  out += (int64_t)blockIdx.y * n;
-  uint32_t c[4] = {(uint32_t)blk, subseq0 + blockIdx.y, stream_lo, stream_hi};
-  philox4x32_10(c, seed_lo, seed_hi);
-  float z[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u0 = ((float)(c[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float u1 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float rad = sqrtf(-2.0f * logf(u0));
-    const float ang = 6.283185307179586f * u1;
-    z[2 * h] = rad * cosf(ang);
-    z[2 * h + 1] = rad * sinf(ang);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (blk * 4 + j < n) out[blk * 4 + j] = z[j];
 }
 
 // fp32 -> bf16 planes (test helper for the standalone ops)

@@ -133,9 +133,8 @@ struct msd_model {
   float* h32 = nullptr;
   float* eps = nullptr;
   float* z = nullptr;
-  float* noise_own = nullptr;
-  size_t noise_own_elems = 0;
   const float** d_noise_slot = nullptr;
+  uint32_t* d_rng_key = nullptr;       // {seed_lo, seed_hi, stream_lo, stream_hi} of the current msd_sample (elementwise.h SamplerParams::rng_key)
   int* d_step = nullptr;       // [2]
   int* d_nkeys_self = nullptr; // [passes*Bmax] = T
   int* d_nkeys_cross = nullptr;// [n_cross][Bmax] valid keys per key region and song
@@ -1171,7 +1170,7 @@ void enqueue_step(Ctx& c, int batch) {
   in_proj<NP>(c, batch, dedup0 ? 1 : P, /*publish_step=*/true);
   decoder_layers<NP>(c, batch, P, true, dedup0);
   SamplerParams sp;
-  sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef;
+  sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef; sp.rng_key = m->d_rng_key;
   sp.step_ptr = m->d_step; sp.n = batch * m->T * m->ND; sp.passes = P;
   sp.cond_wt = m->cfg.cfg_weight; sp.clip_x0 = m->cfg.clip_x0;
   sp.ddim = m->cfg.sampler == MSD_SAMPLER_DDIM;
@@ -1326,6 +1325,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(dalloc(m, &m->eps, Mmax * m->ND));
   TRY(dalloc(m, &m->z, (size_t)m->Bmax * T * m->ND));
   TRY(dalloc(m, &m->d_noise_slot, 1));
+  TRY(dalloc(m, &m->d_rng_key, 4));
   TRY(dalloc(m, &m->d_step, 2));
   TRY(dalloc(m, &m->d_absmax, 1));
   TRY(dalloc(m, &m->d_sat, 1));
@@ -1368,7 +1368,6 @@ void msd_destroy(msd_model* m) {
   if (m->prof.e0) (void)hipEventDestroy(m->prof.e0);
   if (m->prof.e1) (void)hipEventDestroy(m->prof.e1);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
-  if (m->noise_own) (void)hipFree(m->noise_own);
   if (m->h_sat) (void)hipHostFree(m->h_sat);
   for (void* p : m->allocs) (void)hipFree(p);
   delete m;
@@ -1394,9 +1393,13 @@ int msd_set_weight(msd_model* m, const char* name, const float* data, const int6
   if (!ok)
     return fail(m, MSD_ERR_SHAPE_MISMATCH, "weight '%s': expected [%lld,%lld] (ndim %d)", name,
                 (long long)w.shape[0], (long long)w.shape[1], w.ndim);
-  if (!w.dev)
-    return fail(m, MSD_ERR_BAD_STATE, "weight '%s': msd_finalize_weights has run and freed its staging copy (weights are "
-                "loaded once per handle; create a new model)", name);
+  // Weights are loaded ONCE per handle: after msd_finalize_weights every msd_set_weight is refused -- also for a weight
+  // whose float32 copy is still resident (norm scales, embeddings, keep_raw_weights = 1): accepting it used to clear
+  // `finalized` while a second msd_finalize_weights refuses ("already finalized"), which left the handle unusable and
+  // the new values unused.
+  if (m->dec.size() || !w.dev)
+    return fail(m, MSD_ERR_BAD_STATE, "weight '%s': msd_finalize_weights has run (weights are loaded once per handle; "
+                "create a new model)", name);
   HIP_TRY(m, copy_sync(m, w.dev, data, (size_t)w.numel() * sizeof(float), hipMemcpyDefault));
   w.set = true;
   m->finalized = false;
@@ -1503,7 +1506,10 @@ int msd_encode(msd_model* m, int batch, const int32_t* tokens, const float* ctx_
   if (m->cfg.has_context && (!ctx_dev || !ctx_mask))
     return fail(m, MSD_ERR_INVALID_ARGUMENT, "context model needs ctx and ctx_mask");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // tokens / mask may live on either side: stage them on the host (a few KiB)
+  // tokens / mask may live on either side: stage them on the host (a few KiB).  The staging copies run on the handle's
+  // own stream (copy_sync): a DEVICE-side tokens / mask buffer the caller is still writing on `stream` must be complete
+  // first -- one synchronisation of the caller's stream orders it (microseconds against a ~1 s segment).
+  HIP_TRY(m, hipStreamSynchronize(s));
   std::vector<int32_t> tok_h((size_t)batch * m->L), mask_h;
   HIP_TRY(m, copy_sync(m, tok_h.data(), tokens, tok_h.size() * sizeof(int32_t), hipMemcpyDefault));
   if (m->cfg.has_context) {
@@ -1540,8 +1546,12 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   if (!out_dev) return fail(m, MSD_ERR_INVALID_ARGUMENT, "out is null");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool null_stream = (s == nullptr);
-  if (null_stream) {  // the legacy NULL stream cannot be captured: run on our own stream
-    HIP_TRY(m, hipDeviceSynchronize());
+  if (null_stream) {
+    // The legacy NULL stream cannot be captured: the call runs on the handle's own (non-blocking) stream.  What the
+    // caller enqueued on the NULL stream before this call (its init_z / noise / out buffers) is ordered in front by ONE
+    // hipStreamSynchronize of the NULL stream -- NOT hipDeviceSynchronize (round 5): that waited for every other handle's
+    // stream on the device as well, against the header's "handles are independent, also on one device".
+    HIP_TRY(m, hipStreamSynchronize(nullptr));
     s = m->own_stream;
   }
   const int64_t n = (int64_t)batch * m->T * m->ND;
@@ -1554,22 +1564,14 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
     if (rc) return fail(m, rc, "philox fill failed");
   }
   split_z(m, n, s);
+  // Step noise: the caller's buffer, or -- noise_dev == NULL -- drawn INSIDE sampler_step_kernel (round 6): step i's draw is
+  // sub-sequence 1 + i of the (seed, stream_id) Philox stream, the row philox_normal_kernel used to write into an
+  // [N][n] buffer up front (131 MB x songs at base, with a hipMalloc in here on the first call of a batch size).  Same
+  // function, same counters: bit-identical to the buffered form (tests/test_gpu_model.py).  The slot holds NULL then.
   const float* noise = noise_dev;
-  if (ddpm && !noise) {
-    const size_t need = (size_t)m->N * n;
-    if (m->noise_own_elems < need) {
-      if (m->noise_own) (void)hipFree(m->noise_own);
-      m->noise_own = nullptr; m->noise_own_elems = 0;
-      HIP_TRY(m, hipMalloc(&m->noise_own, need * sizeof(float)));
-      m->noise_own_elems = need;
-    }
-    const int64_t blocks4 = (n + 3) / 4;
-    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((blocks4 + 255) / 256), m->N), dim3(256), 0, s,
-                       m->noise_own, n, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id,
-                       (uint32_t)(stream_id >> 32), 1u);
-    HIP_TRY(m, hipGetLastError());
-    noise = m->noise_own;
-  }
+  const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  HIP_TRY(m, hipMemcpyAsync(m->d_rng_key, key, sizeof(key), hipMemcpyHostToDevice, s));
+  (void)ddpm;
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
@@ -1694,15 +1696,19 @@ int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t ma
   if (n_out) *n_out = count;
   const int64_t n = count < max_elems ? count : max_elems;
   if (n <= 0) return MSD_OK;
+  // A debug entry point: waits for the whole device (whatever stream the caller ran the model on), then copies and merges
+  // planes through the handle's own stream like every other synchronous copy of the library -- never through the legacy
+  // stream, whose operations fail while another thread captures a step graph on a blocking stream (the
+  // library's own captures are hipStreamCaptureModeThreadLocal, under which another thread's device-wide wait is legal).
   HIP_TRY(m, hipDeviceSynchronize());
   if (f32) {
-    HIP_TRY(m, hipMemcpy(host_out, f32, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(m, copy_sync(m, host_out, f32, n * sizeof(float), hipMemcpyDeviceToHost));
   } else {
     float* tmp = nullptr;
     HIP_TRY(m, hipMalloc(&tmp, n * sizeof(float)));
-    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, pl->p[0],
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->own_stream, pl->p[0],
                        m->NP == 2 ? pl->p[1] : (const h16_t*)nullptr, tmp, n);
-    hipError_t e = hipMemcpy(host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
+    hipError_t e = copy_sync(m, host_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     HIP_TRY(m, e);
   }
@@ -1720,19 +1726,9 @@ int msd_profile_steps(msd_model* m, int batch, int n_steps, const char* const** 
   int rc = msd_fill_normal(1, 0, 0, m->z, n, s);
   if (rc) return rc;
   split_z(m, n, s);
-  const float* noise = m->noise_own;
-  if (m->cfg.sampler == MSD_SAMPLER_DDPM && m->noise_own_elems < (size_t)m->N * n) {
-    // profile against the z buffer itself as a stand-in noise source is not valid:
-    // allocate the real buffer once.
-    if (m->noise_own) (void)hipFree(m->noise_own);
-    m->noise_own = nullptr; m->noise_own_elems = 0;
-    HIP_TRY(m, hipMalloc(&m->noise_own, (size_t)m->N * n * sizeof(float)));
-    m->noise_own_elems = (size_t)m->N * n;
-    const int64_t blocks4 = (n + 3) / 4;
-    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((blocks4 + 255) / 256), m->N), dim3(256), 0, s,
-                       m->noise_own, n, 1u, 0u, 0u, 0u, 1u);
-    noise = m->noise_own;
-  }
+  const float* noise = nullptr;   // the sampler kernel draws the steps' noise itself (Philox stream (1, 0): elementwise.h)
+  const uint32_t key[4] = {1u, 0u, 0u, 0u};
+  HIP_TRY(m, hipMemcpyAsync(m->d_rng_key, key, sizeof(key), hipMemcpyHostToDevice, s));
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import time
+
 import numpy as np
 
 
@@ -90,11 +92,15 @@ class _Outbox:
     self.pending = []
 
   def post(self, msg, dst: int, group=None, tag: int = 0):
-    # Plain isend on every backend.  On NCCL / RCCL a plain point-to-point call gets a communicator and a stream PER
-    # PEER PAIR, so this rank's send to r+1 and its receive from r-1 are independent; batch_isend_irecv (round 4) puts
-    # both on the group-wide communicator's one stream, where the receive of song j+1 queues behind the still pending
-    # send of song j -- no deadlock, but no overlap either.  NCCL ignores `tag`: the ORDER is enforced by
-    # the header check in unpack_handoff, not by the transport.
+    # Plain isend on every backend.  batch_isend_irecv (round 4) puts a rank's send and receive on the group-wide
+    # communicator's ONE stream, where the receive of song j+1 queues behind the still pending send of song j -- no
+    # deadlock, but no overlap either.  What a plain isend / recv pair gets from torch's NCCL / RCCL
+    # backend depends on the torch version: older ones create a communicator and a stream per peer pair; with eager
+    # initialisation (`device_id=` at init_process_group, as bench.py does) and a warm-up collective, point-to-point
+    # calls may instead reuse the group's communicator with a stream per pair.  Either way send and receive are not on
+    # one stream, but that THIS rank's send to r+1 overlaps its receive from r-1 on RCCL is UNVERIFIED: no multi-GPU
+    # box has run this; correctness does not depend on it (the chain resolves from the last rank).  NCCL
+    # ignores `tag`: the ORDER is enforced by the header check in unpack_handoff, not by the transport.
     works = [_dist().isend(msg, dst=dst, group=group, tag=tag)]
     self.pending.append((works, msg))
 
@@ -110,6 +116,14 @@ def _recv(buf, src: int, group=None, tag: int = 0):
 
 
 _warmed = set()
+last_warm_up = None   # seconds the last warm_up spent in its collective / its point-to-point chain (bench.py reports it)
+
+
+def _global_rank(group, group_rank: int) -> int:
+  """rank inside `group` -> the global rank isend / recv address"""
+  if group is None:
+    return group_rank
+  return _dist().get_global_rank(group, group_rank)
 
 
 def warm_up(group=None, comm_device='cpu'):
@@ -124,10 +138,34 @@ def warm_up(group=None, comm_device='cpu'):
     return
   import torch
   on_nccl = dist.get_backend(group) == 'nccl'
-  t = torch.zeros(1, dtype=torch.float32, device=comm_device if on_nccl else 'cpu')
+  dev = comm_device if on_nccl else 'cpu'
+  t0 = time.perf_counter()
+  t = torch.zeros(1, dtype=torch.float32, device=dev)
   dist.all_reduce(t, group=group)
   if on_nccl:
     torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  # ... and ONE 4-byte message down the chain r -> r+1 (round 6): whatever the backend sets up per peer pair at the first
+  # point-to-point call (a communicator or a stream on RCCL, a TCP pair on gloo) is set up HERE, outside every timed
+  # region -- the wavefront's first hand-off used to pay it inside the `handoff` leg's clock.  isend first (asynchronous),
+  # then the blocking recv: the chain resolves from rank 0.
+  rank, world = dist.get_rank(group), dist.get_world_size(group)
+  if world > 1:
+    work = None
+    if rank + 1 < world:
+      ping = torch.full((1,), float(rank), dtype=torch.float32, device=dev)
+      work = dist.isend(ping, dst=_global_rank(group, rank + 1), group=group)
+    if rank > 0:
+      pong = torch.empty((1,), dtype=torch.float32, device=dev)
+      dist.recv(pong, src=_global_rank(group, rank - 1), group=group)
+      if float(pong.item()) != float(rank - 1):
+        raise HandoffError('warm-up message from rank %d carried %r' % (rank - 1, pong.item()))
+    if work is not None:
+      work.wait()
+    if on_nccl:
+      torch.cuda.synchronize()
+  global last_warm_up
+  last_warm_up = {'collective_s': round(t1 - t0, 4), 'p2p_chain_s': round(time.perf_counter() - t1, 4)}
   _warmed.add(key)
 
 

@@ -559,9 +559,13 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
         {'encoder_input_tokens': np.concatenate([msd_amd.synthetic.segment_tokens(spec, 40 + b) for b in range(nb)], 0)}
     init_z, noise = philox.segment_noise((nb, t, 128), steps, seed=5, segment=0)
     outs = {}
+    # weight_prefetch=True: the K / V touches ride on the launch's weight-prefetch wave, which the library turns OFF by
+    # itself for models whose step fits the 256 MB cache (tiny_context, small) -- without forcing it the touch variants
+    # of those presets would compare identical code paths
     for name, kw in (('default', {}), ('dedup_layer0 off', dict(dedup_layer0=False)),
-                     ('kv_touch_ahead off', dict(kv_touch_ahead=0)),
-                     ('kv_touch_ahead 5', dict(kv_touch_ahead=5))):
+                     ('kv_touch_ahead off', dict(kv_touch_ahead=0, weight_prefetch=True)),
+                     ('kv_touch_ahead 2', dict(kv_touch_ahead=2, weight_prefetch=True)),
+                     ('kv_touch_ahead 5', dict(kv_touch_ahead=5, weight_prefetch=True))):
       model = msd_amd.InferenceModel(params, spec, batch_size=nb, **kw, **helpers.ALL_PLANES)
       got, _ = model.predict(batch, init_z=init_z, noise=noise)
       outs[name] = np.asarray(got)
@@ -569,6 +573,34 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
     assert np.isfinite(outs['default']).all()
     for name, got in outs.items():
       assert np.array_equal(got, outs['default']), (preset, nb, name, np.abs(got - outs['default']).max())
+
+
+@pytest.mark.parametrize('preset,nb', [('tiny_context', 1), ('tiny_context', 3), ('small', 1)])
+def test_sampler_draws_the_step_noise_itself_bit_identical(preset, nb):
+  """msd_sample with noise == NULL (round 6): sampler_step_kernel draws step i's noise from sub-sequence 1 + i of the
+  (seed, segment) Philox stream -- the [N][batch T n] buffer philox_normal_kernel used to fill up front (131 MB x songs at
+  base, a hipMalloc inside msd_sample) is gone.  Same generator function, same counters: the segment must be
+  BIT-identical to a run that is handed exactly those rows (msd_fill_normal) as explicit noise."""
+  import torch
+  from msd_amd import native
+  steps = 7
+  spec = msd_amd.config.preset(preset, num_steps=steps)
+  t = spec.task_feature_lengths['targets']
+  batch = helpers.make_batch(spec, batch=nb, ctx_mask='ones') if spec.has_context else \
+      {'encoder_input_tokens': np.concatenate([msd_amd.synthetic.segment_tokens(spec, 60 + b) for b in range(nb)], 0)}
+  model = msd_amd.InferenceModel('synthetic:1', spec, batch_size=nb)
+  model.predict(batch, init_z=np.zeros((nb, t, 128), np.float32), noise=np.zeros((steps, nb, t, 128), np.float32))   # graphs captured, tables built
+  got, _ = model.predict(batch, seed=42, segment=3)
+  z = torch.empty((nb, t, 128), dtype=torch.float32, device='cuda')
+  nz = torch.empty((steps, nb, t, 128), dtype=torch.float32, device='cuda')
+  native.fill_normal(z, 42, 3, 0)
+  for i in range(steps):
+    native.fill_normal(nz[i], 42, 3, 1 + i)
+  torch.cuda.synchronize()
+  want, _ = model.predict(batch, init_z=z, noise=nz)
+  assert np.isfinite(got).all() and np.array_equal(np.asarray(got), np.asarray(want)), np.abs(np.asarray(got) - np.asarray(want)).max()
+  other, _ = model.predict(batch, seed=42, segment=4)
+  assert helpers.rms(got, other) > 0.05                     # the segment index keys the stream
 
 
 def test_staging_copies_of_packed_weights_are_freed():
@@ -591,8 +623,15 @@ def test_staging_copies_of_packed_weights_are_freed():
     if not keep:
       nm = model._get_native()
       name = 'decoder/layers_0/mlp/wo/kernel'
-      with pytest.raises(RuntimeError, match='freed its staging copy'):
+      with pytest.raises(RuntimeError, match='loaded once per handle'):
         nm.set_weight(name, params[name])
+    # ... and so is a weight whose float32 copy is still resident (a norm scale; every weight with keep_raw_weights):
+    # accepting it used to clear `finalized` while a second msd_finalize_weights refuses -- a dead handle
+    nm = model._get_native()
+    with pytest.raises(RuntimeError, match='loaded once per handle'):
+      nm.set_weight('decoder/decoder_norm/scale', params['decoder/decoder_norm/scale'])
+    again, _ = model.predict(batch, seed=1)
+    assert np.array_equal(np.asarray(again), np.asarray(outs[keep]))   # the handle is still usable
     del model
   assert np.array_equal(np.asarray(outs[True]), np.asarray(outs[False]))
   assert used[True] - used[False] > 0.6 * matrices, (used, matrices)   # (the allocator returns whole 2 MiB blocks: measured 0.77)
