@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-6 GPU sessions (gpurun -- 'bash tools/ab/r06_session.sh <what> <tag>').
+#   first   new GPU tests (in-kernel step noise, refused late set_weight, touch variants with the prefetch wave forced on)
+#           + the default bench line with its own rocprofv3 legs (base + small) + PMC passes of the `small` preset
+#   tests   full -m gpu suite
+#   final   tests + smoke + tools/profile_round.sh (base) + default bench on the shipped binary
+WHAT=${1:-first}; TAG=${2:-r06a}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT
+sha256sum $ROOT/music-spectrogram-diffusion_amd/csrc/libmsd_amd.so | cut -c1-16 > $OUT/${TAG}_library_sha.txt
+case $WHAT in
+first)
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "draws_the_step_noise or staging or exact_launch or philox or explicit_noise" > $OUT/${TAG}_new_tests.log 2>&1; tail -5 $OUT/${TAG}_new_tests.log
+  mkdir -p $OUT/${TAG}_selfprof
+  timeout 600 python bench.py --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 600 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
+  PRESET=small SKIP_TRACE=1 bash tools/profile_round.sh ${TAG}_small
+  ;;
+tests)
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
+  grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
+  ;;
+esac
+ls -la $OUT | tail -20
