@@ -129,6 +129,7 @@ def roofline_from_self_profile(spec, sp, passes, planes, graph_step_ms=None):
   for c, e in sp['per_class'].items():
     tf = flops.get(c, 0.0) / (e['avg_us'] * 1e-6) / 1e12
     table[c] = {'us_per_launch': e['avg_us'], 'launches_per_step': e['launches_per_step'], 'kernel': e['kernel'],
+                'gap_before_us': e.get('avg_gap_before_us'),
                 'algorithmic_gflop': round(flops.get(c, 0.0) / 1e9, 4), 'tflops': round(tf, 2),
                 'frac': round(tf / PEAK_BF16_TFLOPS, 5)}
   dom = max(table, key=lambda c: flops.get(c, 0.0) * (table[c]['launches_per_step'] or 0.0))
@@ -138,6 +139,9 @@ def roofline_from_self_profile(spec, sp, passes, planes, graph_step_ms=None):
            'launches': round(sum(e['launches_per_step'] or 0.0 for e in table.values()), 1),
            'tflops_over_kernel_time': round(step_flops / (sum_us * 1e-6) / 1e12, 2),
            'frac_over_kernel_time': round(step_flops / (sum_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 5)}
+  for k in ('sum_gap_us_per_step', 'step_span_us', 'gap_between_steps_us'):
+    if k in sp:
+      whole[k] = sp[k]
   if graph_step_ms:
     whole['graph_ms'] = round(graph_step_ms, 4)
     whole['achieved_tflops_graph'] = round(step_flops / (graph_step_ms * 1e-3) / 1e12, 3)
@@ -215,8 +219,6 @@ def classify_kernel(name, step_kernels=None):
   only and averaged the encoder's M = 2048 launches into the decoder's counters (VERDICT r03 weak #3)."""
   if step_kernels is not None and normalise_kernel(name) not in step_kernels:
     return None
-  has_cross = step_kernels is not None and any('EpiStoreH16' in k or 'attention_merge' in k or 'attention_kernel<2, 2, 2' in k
-                                               for k in step_kernels)
   if step_kernels is not None and 'EpiResidualNorm' in name:
     # round 5: layer 0's self-attention block runs on one CFG pass's rows (S5): its out-projection is the duplicating
     # epilogue EpiResidualNorm<2, true> (M = 256) -- a class of its own, one launch per step
@@ -227,10 +229,6 @@ def classify_kernel(name, step_kernels=None):
       for sub, cls in (('32, 48, 4', 'gemm_mlp_out'), ('64, 32, 4', 'gemm_attn_out'), ('32, 32, 4', 'gemm_cross_out')):
         if sub in name:
           return cls
-    if not has_cross:
-      # a model without cross-attention (`small`): the residual template's ONE instantiation serves both the attention
-      # output projection and the MLP output projection
-      return 'gemm_attn_out+gemm_mlp_out'
   if step_kernels is not None and 'EpiQKV' in name and '64, 64, 3' in name and any('64, 96, 3' in k and 'EpiQKV' in k for k in step_kernels):
     return 'gemm_qkv_l0'      # layer 0's QKV projection on M = 256 rows (S5): 64 x 64 tiles, one launch per step
   for sub, cls in KERNEL_CLASSES:
@@ -275,6 +273,102 @@ def kernel_stats_classes(stats_csv):
   return out, steps
 
 
+def kernel_type(name):
+  """Coarse type of a kernel from its demangled name (what the name alone can tell)."""
+  for sub, typ in (('sampler_step_kernel', 'sampler'), ('final_proj_f32_kernel', 'final'), ('EpiInProj', 'in_proj'),
+                   ('EpiQKV', 'qkv'), ('EpiGeglu', 'mlp_in'), ('EpiStoreH16', 'cross_q'),
+                   ('attention_merge_kernel', 'merge'), ('attention_kernel', 'attn'), ('EpiResidualNorm', 'resid')):
+    if sub in name:
+      return typ
+  return None
+
+
+def kernel_trace_classes(trace_csv):
+  """rocprofv3 `*_kernel_trace.csv` (one row per dispatch, with timestamps) -> per-class figures by POSITION in the
+  DDPM step.  A step is the run of dispatches from an input projection to the next sampler launch; inside it the class
+  of a launch follows from its type and its predecessor (the first attention after a QKV projection is the
+  self-attention, a residual GEMM after it the attention output projection, after a cross-attention / its merge the
+  cross output projection, after the gated MLP input the MLP output) -- so instantiations that serve several launch
+  sites (`small`: one residual template for three of them, one attention kernel for both attentions) still classify,
+  which the name-based stats table cannot do.  Also the GAPS: start of a launch minus end of its predecessor.
+  Returns ({class: {kernel, calls, avg_us, launches_per_step, avg_gap_before_us}}, steps, whole-step dict)."""
+  import csv
+  rows = []
+  with open(trace_csv) as f:
+    for r in csv.DictReader(f):
+      name = r.get('Kernel_Name', '')
+      if 'msd::' not in name:
+        continue
+      rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), name))
+  rows.sort()
+  out, steps = {}, 0
+  step_span = step_kernel = step_gap = inter_step = 0.0
+  i, n = 0, len(rows)
+  prev_step_end = None
+  while i < n:
+    if kernel_type(rows[i][2]) != 'in_proj':
+      i += 1
+      continue
+    j = i
+    while j < n and kernel_type(rows[j][2]) != 'sampler':
+      j += 1
+      if j < n and kernel_type(rows[j][2]) == 'in_proj':   # (a decoder pass without a sampler: msd_decoder_pass) not a step
+        break
+    if j >= n or kernel_type(rows[j][2]) != 'sampler':
+      i = j
+      continue
+    seq = rows[i:j + 1]
+    dedup = any('EpiResidualNorm<2, true>' in r[2] for r in seq)
+    prev_cls, first_qkv = None, True
+    for k, (t0, t1, name) in enumerate(seq):
+      typ = kernel_type(name)
+      if typ == 'qkv':
+        cls = 'gemm_qkv_l0' if (dedup and first_qkv) else 'gemm_qkv'
+        first_qkv = False
+      elif typ == 'attn':
+        cls = 'attn_self' if prev_cls in ('gemm_qkv', 'gemm_qkv_l0') else 'attn_cross'
+      elif typ == 'resid':
+        if prev_cls == 'attn_self':
+          cls = 'gemm_attn_out_l0' if 'EpiResidualNorm<2, true>' in name else 'gemm_attn_out'
+        elif prev_cls == 'gemm_mlp_in_geglu':
+          cls = 'gemm_mlp_out'
+        else:
+          cls = 'gemm_cross_out'
+      else:
+        cls = {'sampler': 'sampler_step', 'final': 'final_proj_f32', 'in_proj': 'in_proj_f32', 'mlp_in': 'gemm_mlp_in_geglu',
+               'cross_q': 'gemm_cross_q', 'merge': 'attn_cross_merge'}.get(typ)
+      if cls is None:
+        continue
+      e = out.setdefault(cls, {'kernel': set(), 'calls': 0, '_ns': 0.0, '_gap': 0.0})
+      e['kernel'].add(normalise_kernel(name))
+      e['calls'] += 1
+      e['_ns'] += t1 - t0
+      if k > 0:
+        e['_gap'] += t0 - seq[k - 1][1]
+        step_gap += t0 - seq[k - 1][1]
+      step_kernel += t1 - t0
+      prev_cls = cls
+    steps += 1
+    step_span += seq[-1][1] - seq[0][0]
+    if prev_step_end is not None and seq[0][0] - prev_step_end < 50000:   # consecutive steps of one segment
+      inter_step += seq[0][0] - prev_step_end
+    prev_step_end = seq[-1][1]
+    i = j + 1
+  for e in out.values():
+    e['avg_us'] = round(e['_ns'] / e['calls'] / 1e3, 3)
+    e['avg_gap_before_us'] = round(e.pop('_gap') / e['calls'] / 1e3, 3)
+    e.pop('_ns')
+    e['kernel'] = ' | '.join(sorted(e['kernel']))
+    e['launches_per_step'] = round(e['calls'] / steps, 3) if steps else None
+  whole = {}
+  if steps:
+    whole = {'sum_kernel_us_per_step': round(step_kernel / steps / 1e3, 2),
+             'sum_gap_us_per_step': round(step_gap / steps / 1e3, 2),
+             'step_span_us': round(step_span / steps / 1e3, 2),
+             'gap_between_steps_us': round(inter_step / max(steps - 1, 1) / 1e3, 3)}
+  return out, steps, whole
+
+
 def rocprofv3_path():
   import shutil
   for c in (shutil.which('rocprofv3'), '/opt/rocm/bin/rocprofv3'):
@@ -296,9 +390,11 @@ def self_profile(args, preset, timeout_s=300.0, keep_csv=None):
   if exe is None:
     return None, 'rocprofv3 not found on this box'
   tmp = tempfile.mkdtemp(prefix='msd_selfprof_', dir='/tmp')
+  n_timed = min(args.steps, 2)   # the parent's warm-up segment(s) + its first timed ones: the same key counts, bounded trace size
   cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '--', sys.executable,
          os.path.abspath(__file__), '--self-profile-child', '--preset', preset, '--precision', args.precision,
-         '--num-steps', str(args.num_steps), '--cfg-weight', str(args.cfg_weight)]
+         '--num-steps', str(args.num_steps), '--cfg-weight', str(args.cfg_weight), '--warmup', str(args.warmup),
+         '--steps', str(n_timed), '--data', args.data]
   if args.attn_planes:
     cmd += ['--attn-planes', args.attn_planes]
   env = dict(os.environ)
@@ -312,21 +408,31 @@ def self_profile(args, preset, timeout_s=300.0, keep_csv=None):
         child = json.loads(line)
         break
     stats = sorted(glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True))
-    if run.returncode != 0 or not stats or child is None:
+    trace = sorted(glob.glob(os.path.join(tmp, '**', '*kernel_trace.csv'), recursive=True))
+    if run.returncode != 0 or not (stats or trace) or child is None:
       return None, 'rocprofv3 child failed (rc %s): %s' % (run.returncode, (run.stderr or run.stdout)[-300:])
-    classes, steps = kernel_stats_classes(stats[0])
-    if keep_csv:
+    whole = {}
+    if trace:     # per dispatch: classes by position in the step, and the gaps between launches
+      classes, steps, whole = kernel_trace_classes(trace[0])
+      how = 'per-dispatch kernel trace, classes by position in the step'
+    else:         # (older rocprofv3 without the per-dispatch table) the stats table, classes by kernel name
+      classes, steps = kernel_stats_classes(stats[0])
+      how = 'kernel_stats table, classes by kernel name'
+    if keep_csv and stats:
       shutil.copyfile(stats[0], keep_csv)
     if not classes or not steps:
-      return None, 'no step kernels in the child trace'
-    sum_us = sum(e['avg_us'] * e['calls'] for e in classes.values()) / steps
-    return {'command': 'rocprofv3 --kernel-trace --stats -- python bench.py --self-profile-child --preset %s (one %d-step '
-                       'segment, nothing else; untimed leg of this run)' % (preset, args.num_steps),
-            'steps_traced': steps, 'seconds': round(time.perf_counter() - t0, 1),
-            'child_sample_ms_per_segment': child.get('sample_ms_per_segment'),
-            's_valid_keys': child.get('s_valid_keys'),
-            'sum_kernel_us_per_step': round(sum_us, 2),
-            'per_class': classes}, None
+      return None, 'no DDPM steps in the child trace'
+    sum_us = whole.get('sum_kernel_us_per_step') or sum(e['avg_us'] * e['calls'] for e in classes.values()) / steps
+    rec = {'command': 'rocprofv3 --kernel-trace --stats -- python bench.py --self-profile-child --preset %s --warmup %d --steps %d '
+                      '(the segments this run warms up and starts timing on, nothing else; untimed leg of this run)'
+                      % (preset, args.warmup, n_timed),
+           'read_from': how, 'steps_traced': steps, 'seconds': round(time.perf_counter() - t0, 1),
+           'child_sample_ms_per_segment': child.get('sample_ms_per_segment'),
+           's_valid_keys': child.get('s_valid_keys'),
+           'sum_kernel_us_per_step': round(sum_us, 2),
+           'per_class': classes}
+    rec.update({k: v for k, v in whole.items() if k != 'sum_kernel_us_per_step'})
+    return rec, None
   except subprocess.TimeoutExpired:
     return None, 'rocprofv3 child did not finish within %.0f s' % timeout_s
   except Exception as e:   # never let the profile take the benchmark down
@@ -336,21 +442,36 @@ def self_profile(args, preset, timeout_s=300.0, keep_csv=None):
 
 
 def self_profile_child(args):
-  """What `self_profile` traces: one model, one segment (restore + graph capture + 1000 replayed steps)."""
+  """What `self_profile` traces: one model, the parent's warm-up segment(s) (restore + graph capture) and its first
+  timed segments -- same token seeds, same context chaining, so the key counts (the cross-attention's time) are the
+  parent's."""
   import torch
   import msd_amd
   spec = msd_amd.config.preset(args.preset, num_steps=args.num_steps, cfg_weight=args.cfg_weight)
   model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=1, precision=args.precision, **model_kwargs(args))
   c_len = model.targets_context_length
-  toks = msd_amd.synthetic.segment_tokens(spec, 0)
-  batch = {'encoder_input_tokens': toks}
-  if c_len is not None:   # a realistic key axis: the context is valid (mask 1), as for every segment but a song's first
-    batch['encoder_continuous_inputs'] = torch.zeros((1, c_len, 128), dtype=torch.float32, device=model.device)
-    batch['encoder_continuous_mask'] = np.ones((1, c_len), np.int32)
-  model.predict(batch, seed=0, segment=0, return_torch=True)
+  n_seg = args.warmup + args.steps
+  if args.preset == 'small' and args.data == 'tokens':
+    segs = [msd_amd.synthetic.segment_tokens(spec, 5000 + k) for k in range(n_seg)]       # small_leg's seeds
+  elif args.data == 'midi':
+    segs = synthetic_midi_tokens(spec, 0, n_seg)
+  else:
+    segs = [msd_amd.synthetic.segment_tokens(spec, k) for k in range(n_seg)]              # main()'s song_tokens(0, .)
+  pred = torch.zeros((1, c_len, 128), dtype=torch.float32, device='cuda') if c_len is not None else None
+  smp, keys = [], []
+  for k in range(n_seg):
+    batch = {'encoder_input_tokens': segs[k]}
+    if c_len is not None:
+      batch['encoder_continuous_inputs'] = pred
+      batch['encoder_continuous_mask'] = (np.zeros if k == 0 else np.ones)((1, c_len), np.int32)
+    out, _ = model.predict(batch, seed=0, segment=k, return_torch=True)
+    if c_len is not None:
+      pred = out
+    if k >= args.warmup:
+      smp.append(model.last_timing['sample_s'])
+      keys.append(float((segs[k] > 0).sum() + (c_len if (c_len is not None and k > 0) else 0)))
   torch.cuda.synchronize()
-  print(json.dumps({'sample_ms_per_segment': round(model.last_timing['sample_s'] * 1e3, 3),
-                    's_valid_keys': float((toks > 0).sum() + (c_len or 0))}))
+  print(json.dumps({'sample_ms_per_segment': round(float(np.mean(smp)) * 1e3, 3), 's_valid_keys': float(np.mean(keys))}))
 
 
 def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0):

@@ -41,7 +41,8 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 5   /* 5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
+#define MSD_AMD_ABI_VERSION 6   /* 6: cross_merge_in_launch, cross_q_in_attention appended to msd_config.
+                                   5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
                                    4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
                                       NO environment variable.  3: MSD_ERR_RANGE; distinct bfloat16-plane precisions */
@@ -177,6 +178,15 @@ typedef struct msd_config {
                                      (weight_prefetch off -- the library's choice for models whose step fits the 256 MB
                                      cache, e.g. `small` / tiny presets -- or a module other than a layer's last) never
                                      touches, whatever this field says */
+  /* ABI 6 */
+  int32_t cross_merge_in_launch;  /* a key-split cross-attention finishes INSIDE its launch: every block publishes its
+                                     partial write-through, the last block of a (query tile, head) group to arrive merges
+                                     them -- no separate merge launch (one kernel boundary less per decoder layer);
+                                     bit-identical to the merge launch.  0 = the library's choice (on), 1 = on, 2 = off */
+  int32_t cross_q_in_attention;   /* the cross-attention's query projection runs inside the attention launch (each block
+                                     projects its own 64 x 64 query tile from the normed rows while its first K / V
+                                     stage lands) instead of as a GEMM launch of its own; bit-identical.  0 = the
+                                     library's choice, 1 = on, 2 = off */
 } msd_config;
 
 const char* msd_version(void);
@@ -284,6 +294,12 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev,
 int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* k_dev,
                         const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
                         int heads, void* stream);
+/* ABI 6: the same with the key axis split over `ksplit` blocks per (head, query tile) (a power of two is used: 3 runs as 2)
+ * and the partials merged by the separate merge launch (merge_in_launch = 0) or inside the attention launch by the last
+ * block of each group to arrive (1; attention.h attention_inlaunch_merge); launched `repeats` times back to back. */
+int msd_op_attention_split(int precision, int qp, int ksplit, int merge_in_launch, int repeats, const float* q_dev,
+                           const float* k_dev, const float* v_dev, float* o_dev, int n_q, int n_keys,
+                           int n_keys_valid, int heads, void* stream);
 
 
 /* Standalone forms of the FUSED kernels of the step (each restates one reference function and has its

@@ -60,6 +60,9 @@ struct AttnParams {
   int allow_qb4 = 0;         // host only: this launch may run on 128-row blocks (attention_query_blocks)
   int touch_ahead = 0;       // > 0 (launches with a prefetch wave only): that wave also touches the K / V^T lines of the
                              // block's ring stages this many stages AHEAD of their LDS-DMA (kv_touch_ahead below)
+  int* tickets = nullptr;    // ksplit > 1, in-launch merge (round 6, attention_inlaunch_merge below): one arrival counter per
+                             // (segment, query block of this launch, head), all zero between launches; nullptr = the
+                             // separate attention_merge_kernel launch finishes the split
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -168,6 +171,87 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA of this wave outlives it (the LDS goes back with the block)
   }
+}
+
+// Finish one (row, head, 8-wide d group) of a key-split attention from the KS partials (m, l) and O (relative to its own
+// m): out = sum_ks O_ks e^(m_ks - m) / sum_ks l_ks e^(m_ks - m), sums in split order.  ONE function for the separate merge
+// launch and for the in-launch merge below, so that both write the same bits.
+template <int KS>
+__device__ __forceinline__ void merge_split_partials(const f32x2 (&ml)[KS], const f32x4 (&oa)[KS], const f32x4 (&ob)[KS],
+                                                     float (&v)[8]) {
+  float mt = -1e30f, lt = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) mt = fmaxf(mt, ml[ks][0]);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float f = fast_exp(ml[ks][0] - mt);
+    lt += ml[ks][1] * f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] += oa[ks][e] * f; acc[4 + e] += ob[ks][e] * f; }
+  }
+  const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+}
+
+// In-launch merge of a key-split attention (round 6; VERDICT r05 next #1b): the separate merge launch cost 4.8 us per layer
+// for 1.2 us of work -- a kernel boundary.  Here every block of a (segment, query block, head) group publishes its partial
+// WRITE-THROUGH (sc1 stores: the bytes are at the memory side, visible to every XCD, once the storing wave's vmcnt has
+// drained -- no release fence, which would write back the XCD's whole L2), takes a ticket on the group's counter
+// (relaxed, agent scope), and the block that draws the LAST ticket reads all KS partials back with sc1 loads (they bypass
+// this CU's L1 and are served coherently: no acquire fence), merges them with the function above and stores the planes.
+// MI355X guide, Guideline 16 recipe R1 / the split-K reducer: {sc1 payload -> every storing wave vmcnt(0) -> barrier ->
+// one lane's ticket}, reducer: sc1 loads.  Placement-independent: nothing here depends on which XCD a block runs on.
+// Round 3's attempt (+10 ... 50 us per launch, docs/history.md) used __threadfence() on both sides: buffer_wbl2 +
+// buffer_inv in every block.  The counter is zero between launches: the reducer resets it (msd_sample zeroes the array
+// once at its start, in case an aborted launch left a count behind).  `slot` = 4 bytes of LDS nobody else uses by now.
+template <int NP, int KS>
+__device__ __forceinline__ void attention_inlaunch_merge(const AttnParams& p, int ks, size_t row, int head, int heads, int d0,
+                                                         const float (&acc)[8], float mt, float lt, int group, int tid,
+                                                         int* slot) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  const size_t rows = (size_t)p.total_rows;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.part_o, 0, (int)((size_t)p.ksplit * rows * heads * 64 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(p.part_ml, 0, (int)((size_t)p.ksplit * rows * heads * 2 * 4), 0x00020000);
+  const int item = (int)(row * heads + head);          // (row, head) of this thread, as the merge launch indexes them
+  const int stride = (int)(rows * heads);              // items per split
+  {
+    const int base = ks * stride + item;
+    const u4 a = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+    const u4 b = {__float_as_uint(acc[4]), __float_as_uint(acc[5]), __float_as_uint(acc[6]), __float_as_uint(acc[7])};
+    __builtin_amdgcn_raw_buffer_store_b128(a, ro, (base * 64 + d0) * 4, 0, /*sc1*/ 16);
+    __builtin_amdgcn_raw_buffer_store_b128(b, ro, (base * 64 + d0 + 4) * 4, 0, 16);
+    if (d0 == 0) {
+      const u2 m2 = {__float_as_uint(mt), __float_as_uint(lt)};
+      __builtin_amdgcn_raw_buffer_store_b64(m2, rm, base * 8, 0, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) ; msd publish drain" ::: "memory");   // EVERY storing wave (guide G16 pitfall 14)
+  __syncthreads();
+  if (tid == 0) *slot = __hip_atomic_fetch_add(p.tickets + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*slot != KS - 1) return;                         // (block-uniform) not the last arriver: done
+  f32x2 ml[KS];
+  f32x4 oa[KS], ob[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int base = k * stride + item;
+    const u2 m2 = __builtin_amdgcn_raw_buffer_load_b64(rm, base * 8, 0, 16);
+    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(ro, (base * 64 + d0) * 4, 0, 16);
+    const u4 b = __builtin_amdgcn_raw_buffer_load_b128(ro, (base * 64 + d0 + 4) * 4, 0, 16);
+    ml[k] = f32x2{__uint_as_float(m2[0]), __uint_as_float(m2[1])};
+    oa[k] = f32x4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
+    ob[k] = f32x4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+  }
+  float v[8];
+  merge_split_partials<KS>(ml, oa, ob, v);
+  RangeCheck rc;
+  store_h16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v, rc);
+  rc.commit(p.sat, p.sat_tag);
+  if (tid == 0) __hip_atomic_store(p.tickets + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
 }
 
 // QB query blocks of 32 rows per workgroup (attention_query_blocks above): QB = 2: 64 query rows share each K/V stage;
@@ -478,6 +562,14 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       RangeCheck rc;
       store_h16x8<NP>(p.o, row * p.ldo + head * 64 + d0, v, rc);
       rc.commit(p.sat, p.sat_tag);
+    } else if (p.tickets != nullptr) {
+      // in-launch merge: group = (segment, query block of the launch, head); the LDS word behind the merge slab is free
+      const int heads = gridDim.x, nblk = (int)(gridDim.y >> kl2);
+      const int group = ((int)seg * nblk + blk) * heads + head;
+      int* slot = reinterpret_cast<int*>(smem + QB * kAttKG * kAttWStride * 4);
+      if (p.ksplit == 4) attention_inlaunch_merge<NP, 4>(p, ks, row, head, heads, d0, acc, mt, lt, group, tid, slot);
+      else if (p.ksplit == 2) attention_inlaunch_merge<NP, 2>(p, ks, row, head, heads, d0, acc, mt, lt, group, tid, slot);
+      else attention_inlaunch_merge<NP, 8>(p, ks, row, head, heads, d0, acc, mt, lt, group, tid, slot);
     } else {
       const int heads = gridDim.x;
       float* po = p.part_o + (((size_t)ks * p.total_rows + row) * heads + head) * 64 + d0;
@@ -513,6 +605,7 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
   float lt = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  float v[8];
   if constexpr (KS > 0) {
     f32x2 ml[KS];
     f32x4 oa[KS], ob[KS];
@@ -523,15 +616,7 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
       oa[ks] = *reinterpret_cast<const f32x4*>(p.part_o + base * 64 + d0);
       ob[ks] = *reinterpret_cast<const f32x4*>(p.part_o + base * 64 + d0 + 4);
     }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) mt = fmaxf(mt, ml[ks][0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float f = fast_exp(ml[ks][0] - mt);
-      lt += ml[ks][1] * f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[e] += oa[ks][e] * f; acc[4 + e] += ob[ks][e] * f; }
-    }
+    merge_split_partials<KS>(ml, oa, ob, v);
   } else {
     for (int ks = 0; ks < p.ksplit; ++ks)
       mt = fmaxf(mt, p.part_ml[(((size_t)ks * p.total_rows + row) * heads + head) * 2]);
@@ -544,11 +629,10 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
       acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
       acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
     }
-  }
-  const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
-  float v[8];
+    const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+    for (int e = 0; e < 8; ++e) v[e] = acc[e] * inv;
+  }
   RangeCheck rc;
   store_h16x8<NP>(p.o, (size_t)row * p.ldo + head * 64 + d0, v, rc);
   rc.commit(p.sat, p.sat_tag);
@@ -633,7 +717,7 @@ inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, 
   } else {
     launch_attention_qp<NP, 0>(p, heads, segs, stream);
   }
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && p.tickets == nullptr) {
     const int items = p.total_rows * heads * 8;
     const dim3 mg((items + 255) / 256), mb(256);
     const unsigned inv_heads = heads > 1 ? (unsigned)((0x100000000ull + (unsigned)heads - 1) / (unsigned)heads) : 0u;

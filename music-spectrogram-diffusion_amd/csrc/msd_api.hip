@@ -158,6 +158,9 @@ struct msd_model {
   bool prefetch = true;        // producers warm the next GEMM's weights (msd_config.weight_prefetch; default: by model size)
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
   int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
+  bool merge_in_launch = true; // attention.h attention_inlaunch_merge (msd_config.cross_merge_in_launch = 2 turns it off)
+  int* att_tickets = nullptr;  // its arrival counters: [Bmax][T / 32][H], zero between launches
+  int att_ticket_count = 0;
   int cus = 0;                 // compute units of the device
   float* d_absmax = nullptr;   // largest |w| over the packed weights (bits, pack_wt_kernel): half-plane range check
   // Query side of the DECODER's self- and cross-attention (attention.h QP bits: 1 = Q enters q.k^T as one plane,
@@ -579,11 +582,13 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   // 128-row blocks (attention.h attention_query_blocks) for the DECODER's attentions at batch: the cross-attention, and
   // the self-attention when its caller has taken the weight target off the launch (an empty, non-null prefetch)
   p.allow_qb4 = kc == KC_ATTN_CROSS || (kc == KC_ATTN_SELF && pf != nullptr && pf->n == 0);
+  // a key-split cross-attention merges its partials inside the launch (attention.h attention_inlaunch_merge)
+  p.tickets = (kc == KC_ATTN_CROSS && ksplit > 1 && c.m->merge_in_launch) ? c.m->att_tickets : nullptr;
   c.begin(kc);
   hipError_t e = launch_attention<NP>(p, heads, segs, c.s);
   if (e != hipSuccess && c.err == hipSuccess) c.err = e;
   c.end(kc);
-  if (c.m->prof.on && ksplit > 1) c.m->prof.launches[kc] += 1;  // + attention_merge_kernel
+  if (c.m->prof.on && ksplit > 1 && p.tickets == nullptr) c.m->prof.launches[kc] += 1;  // + attention_merge_kernel
 }
 
 template <class Epi>
@@ -1201,7 +1206,7 @@ void set_func_attrs() {
 extern "C" {
 
 const char* msd_version(void) {
-  static const std::string v = std::string("msd_amd 0.6.0 (gfx950, abi 5, ") + kPlaneName + ")";
+  static const std::string v = std::string("msd_amd 0.7.0 (gfx950, abi 6, ") + kPlaneName + ")";
   return v.c_str();
 }
 
@@ -1254,6 +1259,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
       cfg->cross_key_split != 8) return bad("cross_key_split must be 0 (chosen per segment), 1, 2, 4 or 8");
   if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
   if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
+  if (cfg->cross_merge_in_launch < 0 || cfg->cross_merge_in_launch > 2) return bad("cross_merge_in_launch must be 0 (library default), 1 (on) or 2 (off)");
+  if (cfg->cross_q_in_attention < 0 || cfg->cross_q_in_attention > 2) return bad("cross_q_in_attention must be 0 (library default), 1 (on) or 2 (off)");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1269,6 +1276,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->weight_prefetch) m->prefetch = cfg->weight_prefetch == 1;   // 0: msd_finalize_weights decides from the sizes
   m->dedup_layer0 = cfg->dedup_layer0 != 2;
   if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
+  m->merge_in_launch = cfg->cross_merge_in_launch != 2;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-
@@ -1311,6 +1319,8 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->cross_ksplit = m->S_pad >= 1024 ? 8 : (m->S_pad >= 512 ? 4 : (m->S_pad >= 256 ? 2 : 1));   // workspace bound
   TRY(dalloc(m, &m->att_part_o, (size_t)m->cross_ksplit * m->Bmax * T * J));
   TRY(dalloc(m, &m->att_part_ml, (size_t)m->cross_ksplit * m->Bmax * T * m->H * 2));
+  m->att_ticket_count = m->Bmax * (T / 32) * m->H;
+  TRY(dalloc(m, &m->att_tickets, (size_t)m->att_ticket_count));   // (zeroed)
   TRY(palloc(m, &m->h, Mmax * D));
   TRY(palloc(m, &m->qk, Mmax * 2 * J));
   TRY(palloc(m, &m->vt, Mmax * J));
@@ -1572,6 +1582,9 @@ int msd_sample(msd_model* m, int batch, uint64_t seed, uint64_t stream_id, const
   const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
   HIP_TRY(m, hipMemcpyAsync(m->d_rng_key, key, sizeof(key), hipMemcpyHostToDevice, s));
   (void)ddpm;
+  // arrival counters of the in-launch merge: zero between launches by construction (the reducer resets its own); once
+  // per call in case an aborted launch left a count behind
+  HIP_TRY(m, hipMemsetAsync(m->att_tickets, 0, (size_t)m->att_ticket_count * sizeof(int), s));
   HIP_TRY(m, hipMemcpyAsync(m->d_noise_slot, &noise, sizeof(float*), hipMemcpyHostToDevice, s));
   const int start[2] = {m->N - 1, m->N - 1};
   HIP_TRY(m, hipMemcpyAsync(m->d_step, start, sizeof(start), hipMemcpyHostToDevice, s));
@@ -1848,7 +1861,15 @@ int msd_op_attention(int precision, const float* q_dev, const float* k_dev, cons
 
 int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* k_dev, const float* v_dev,
                         float* o_dev, int n_q, int n_keys, int n_keys_valid, int heads, void* stream) {
-  if (qp < 0 || qp > 3) return MSD_ERR_INVALID_ARGUMENT;
+  // (long key axes exercise the key-split path + the merge LAUNCH: a split of 3 runs as 2)
+  return msd_op_attention_split(precision, qp, n_keys >= 512 ? 3 : 1, 0, 1, q_dev, k_dev, v_dev, o_dev, n_q, n_keys, n_keys_valid,
+                                heads, stream);
+}
+
+int msd_op_attention_split(int precision, int qp, int ksplit, int merge_in_launch, int repeats, const float* q_dev,
+                           const float* k_dev, const float* v_dev, float* o_dev, int n_q, int n_keys, int n_keys_valid,
+                           int heads, void* stream) {
+  if (qp < 0 || qp > 3 || ksplit < 1 || ksplit > 8 || repeats < 1 || repeats > 1000) return MSD_ERR_INVALID_ARGUMENT;
   if (n_q % 64 || n_keys % 32 || n_q <= 0 || n_keys <= 0 || heads <= 0 || n_keys_valid < 0 ||
       n_keys_valid > n_keys)
     return MSD_ERR_INVALID_ARGUMENT;
@@ -1894,14 +1915,20 @@ int msd_op_attention_qp(int precision, int qp, const float* q_dev, const float* 
   p.k_seg_stride = 0; p.vt_seg_stride = 0; p.k_rows = n_keys;
   p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr; p.total_rows = n_q;
   float *po = nullptr, *pml = nullptr;
-  if (n_keys >= 512) {  // exercise the key-split path + merge kernel on long key axes
-    p.ksplit = 3;
-    po = sc.get<float>((size_t)3 * n_q * J);
-    pml = sc.get<float>((size_t)3 * n_q * heads * 2);
+  if (ksplit > 1) {
+    p.ksplit = ksplit;
+    po = sc.get<float>((size_t)ksplit * n_q * J);
+    pml = sc.get<float>((size_t)ksplit * n_q * heads * 2);
     if (!po || !pml) return MSD_ERR_HIP;
     p.part_o = po; p.part_ml = pml;
+    if (merge_in_launch) {   // attention.h attention_inlaunch_merge: one (zeroed) arrival counter per (query block, head)
+      p.tickets = sc.get<int>((size_t)(n_q / 32) * heads);
+      if (!p.tickets) return MSD_ERR_HIP;
+    }
   }
-  hipError_t e = NP == 2 ? launch_attention<2>(p, heads, 1, s) : launch_attention<1>(p, heads, 1, s);
+  hipError_t e = hipSuccess;
+  for (int r = 0; r < repeats && e == hipSuccess; ++r)   // back to back: the counters must be zero again after every launch
+    e = NP == 2 ? launch_attention<2>(p, heads, 1, s) : launch_attention<1>(p, heads, 1, s);
   if (e != hipSuccess) return MSD_ERR_HIP;
   hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)(((int64_t)n_q * J + 255) / 256)), dim3(256), 0, s,
                      o.p[0], NP == 2 ? o.p[1] : (const h16_t*)nullptr, o_dev, (int64_t)n_q * J);

@@ -26,7 +26,7 @@ MSD_PREC_F16 = 0      # one IEEE-half plane per operand
 MSD_PREC_F16X3 = 1    # hi + lo half planes, three MFMAs per product (the parity mode, the default)
 MSD_PREC_BF16 = 2     # one bfloat16 plane                       } libmsd_amd_bf16.so; msd_create of the other
 MSD_PREC_BF16X3 = 3   # hi + lo bfloat16 planes                  } build answers MSD_ERR_UNSUPPORTED
-ABI_VERSION = 5        # MSD_AMD_ABI_VERSION of include/msd_amd.h (tests/test_abi.py)
+ABI_VERSION = 6        # MSD_AMD_ABI_VERSION of include/msd_amd.h (tests/test_abi.py)
 MSD_SAMPLER_DDPM = 0
 MSD_SAMPLER_DDIM = 1
 MAX_KERNEL_CLASSES = 16
@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = (
     'msd_num_weights', 'msd_weight_info', 'msd_set_weight', 'msd_finalize_weights',
     'msd_encode', 'msd_sample', 'msd_reset_graph', 'msd_decoder_pass', 'msd_fill_normal', 'msd_get_schedule',
     'msd_debug_read', 'msd_profile_steps', 'msd_op_gemm_h16', 'msd_op_gemm_bf16', 'msd_op_gemm_f32',
-    'msd_op_attention', 'msd_op_attention_qp', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
+    'msd_op_attention', 'msd_op_attention_qp', 'msd_op_attention_split', 'msd_op_sampler_step', 'msd_op_residual_norm_gemm', 'msd_op_geglu',
     'msd_op_qkv', 'msd_op_final_proj')
 
 
@@ -73,7 +73,7 @@ MODEL_OUTPUTS = {'eps': MSD_OUTPUT_EPS, 'x0': MSD_OUTPUT_X0, 'v': MSD_OUTPUT_V}
 
 
 class MsdConfig(ctypes.Structure):
-  """msd_config of include/msd_amd.h (ABI 5), field for field."""
+  """msd_config of include/msd_amd.h (ABI 6), field for field."""
   _fields_ = [(n, ctypes.c_int32) for n in (
       'struct_size', 'has_context', 'vocab_size', 'emb_dim', 'num_heads', 'head_dim',
       'mlp_dim', 'num_encoder_layers', 'num_decoder_layers', 'inputs_length',
@@ -89,12 +89,13 @@ class MsdConfig(ctypes.Structure):
       ('attn_q_planes', ctypes.c_int32), ('attn_p_planes', ctypes.c_int32), ('graph_steps', ctypes.c_int32),
       ('weight_prefetch', ctypes.c_int32),
       ('dedup_layer0', ctypes.c_int32), ('cross_key_split', ctypes.c_int32), ('keep_raw_weights', ctypes.c_int32),
-      ('kv_touch_ahead', ctypes.c_int32)]
+      ('kv_touch_ahead', ctypes.c_int32),
+      ('cross_merge_in_launch', ctypes.c_int32), ('cross_q_in_attention', ctypes.c_int32)]
 
 
 # msd_config only ever grows at its end, so an OLDER library can be driven by passing it the struct size it knows
 # (same-box A/B of a previous round's binary through MSD_AMD_LIB: tools/ab/); the newer fields are then simply not seen.
-ABI_STRUCT_SIZES = {4: MsdConfig.weight_prefetch.offset + 4, 5: ctypes.sizeof(MsdConfig)}
+ABI_STRUCT_SIZES = {4: MsdConfig.weight_prefetch.offset + 4, 5: MsdConfig.kv_touch_ahead.offset + 4, 6: ctypes.sizeof(MsdConfig)}
 
 _libs = {}
 
@@ -167,6 +168,8 @@ def load(planes: str = 'f16') -> ctypes.CDLL:
   lib.msd_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   if 'msd_op_attention_qp' in present:
     lib.msd_op_attention_qp.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+  if 'msd_op_attention_split' in present:
+    lib.msd_op_attention_split.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   lib.msd_op_sampler_step.argtypes = [c.POINTER(MsdConfig), i32, vp, vp, vp, vp, vp, i64, vp]
   lib.msd_op_residual_norm_gemm.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
   lib.msd_op_geglu.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
@@ -365,6 +368,20 @@ def op_attention(precision: str, q, k, v, o, heads: int, n_keys_valid: Optional[
                                n_keys, nv, heads, stream)
   if rc:
     raise _EXC.get(rc, RuntimeError)('msd_op_attention failed (%d)' % rc)
+
+
+def op_attention_split(precision: str, q, k, v, o, heads: int, ksplit: int, merge_in_launch: bool, repeats: int = 1,
+                       n_keys_valid: Optional[int] = None, stream: int = 0, qp: int = 0):
+  """op_attention with the key axis split over `ksplit` blocks per (head, query tile); the partials are merged by the
+  separate merge launch or -- merge_in_launch -- inside the attention launch by the last block to arrive; `repeats`
+  launches back to back (the in-launch merge's arrival counters must be zero again after each)."""
+  lib = load(plane_format(precision))
+  n_q, n_keys = q.shape[0], k.shape[0]
+  nv = n_keys if n_keys_valid is None else n_keys_valid
+  rc = lib.msd_op_attention_split(PRECISIONS[precision], qp, ksplit, int(bool(merge_in_launch)), repeats, _ptr(q), _ptr(k),
+                                  _ptr(v), _ptr(o), n_q, n_keys, nv, heads, stream)
+  if rc:
+    raise _EXC.get(rc, RuntimeError)('msd_op_attention_split failed (%d)' % rc)
 
 
 def _op_check(rc, what):

@@ -153,18 +153,50 @@ def test_kernel_stats_classes_of_a_committed_trace():
   assert abs(whole['sum_kernel_us'] - 956.6) < 1.0 and whole['launches'] == 111.0
 
 
-def test_classify_a_model_without_cross_attention():
-  """`small`: no cross block, and the residual template's one instantiation serves attention-out AND MLP-out."""
-  names = {'gemm_h16_dma_kernel<2, 64, 64, 3, EpiQKV<2>, 0>', 'gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, false>, 0>',
-           'gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, true>, 0>', 'gemm_h16_dma_kernel<2, 64, 64, 3, EpiGeglu<2>, 0>',
-           'attention_kernel<2, 2, 1, 0, 0>', 'final_proj_f32_kernel<1>', 'sampler_step_kernel<0>',
-           'gemm_h16_dma_kernel<2, 32, 32, 4, EpiInProj<2>, 0>'}
-  got = {n: bench.classify_kernel('void msd::' + n + '(msd::GemmParams)', names) for n in names}
-  assert got['gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, false>, 0>'] == 'gemm_attn_out+gemm_mlp_out'
-  assert got['gemm_h16_dma_kernel<2, 32, 32, 4, EpiResidualNorm<2, true>, 0>'] == 'gemm_attn_out_l0'
-  assert got['gemm_h16_dma_kernel<2, 64, 64, 3, EpiQKV<2>, 0>'] == 'gemm_qkv' and None not in got.values()
-  flops, _ = bench.class_work(msd_amd.config.preset('small'), 1100.0, 2)
-  assert flops['gemm_attn_out'] < flops['gemm_attn_out+gemm_mlp_out'] < flops['gemm_mlp_out']
+def _write_trace(path, names, dur_ns=5000, gap_ns=2000):
+  import csv
+  t = 0
+  with open(path, 'w') as fh:
+    w = csv.DictWriter(fh, fieldnames=['Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+    w.writeheader()
+    for name in names:
+      w.writerow(dict(Kernel_Name=name, Start_Timestamp=t + gap_ns, End_Timestamp=t + gap_ns + dur_ns))
+      t += gap_ns + dur_ns
+
+
+def test_kernel_trace_classes_by_position_in_the_step(tmp_path):
+  """bench.py's rocprofv3 leg reads the PER-DISPATCH kernel trace: a launch's class follows from its position in the
+  DDPM step, so `small` -- where ONE residual-GEMM instantiation serves attention-out, cross-out and MLP-out and one
+  attention kernel both attentions -- still gets one class per launch site; launches outside a step (encoders) do
+  not count; the gaps between launches are measured."""
+  g = 'void msd::gemm_h16_dma_kernel<2, %s, msd::%s, 0>(msd::GemmParams, msd::X)'
+  att = 'void msd::attention_kernel<2, 2, 1, 0, 0>(msd::AttnParams)'
+  res = g % ('32, 32, 4', 'EpiResidualNorm<2, false>')
+  layer = [g % ('64, 64, 3', 'EpiQKV<2>'), att, res, g % ('32, 32, 4', 'EpiStoreH16<2>'), att,
+           'void msd::attention_merge_kernel<2, 4>(msd::AttnParams, int, unsigned int)', res, g % ('64, 64, 3', 'EpiGeglu<2>'), res]
+  layer0 = list(layer)
+  layer0[2] = g % ('32, 32, 4', 'EpiResidualNorm<2, true>')
+  step = [g % ('32, 32, 4', 'EpiInProj<2>')] + layer0 + layer * 2 + ['void msd::final_proj_f32_kernel<1>(msd::FinalProjParams)',
+                                                                       'void msd::sampler_step_kernel<0>(msd::SamplerParams)']
+  encoder = [g % ('64, 64, 3', 'EpiQKV<2>'), 'void msd::attention_kernel<2, 2, 2, 0, 0>(msd::AttnParams)', g % ('64, 64, 3', 'EpiGeglu<2>')]
+  path = str(tmp_path / 'x_kernel_trace.csv')
+  _write_trace(path, encoder + step * 4)
+  classes, steps, whole = bench.kernel_trace_classes(path)
+  assert steps == 4
+  want = {'in_proj_f32': 1, 'gemm_qkv_l0': 1, 'gemm_qkv': 2, 'attn_self': 3, 'gemm_attn_out_l0': 1, 'gemm_attn_out': 2,
+          'gemm_cross_q': 3, 'attn_cross': 3, 'attn_cross_merge': 3, 'gemm_cross_out': 3, 'gemm_mlp_in_geglu': 3,
+          'gemm_mlp_out': 3, 'final_proj_f32': 1, 'sampler_step': 1}
+  assert {c: e['launches_per_step'] for c, e in classes.items()} == want
+  assert all(e['avg_us'] == 5.0 for e in classes.values())
+  n = len(step)
+  assert whole['sum_kernel_us_per_step'] == 5.0 * n and whole['sum_gap_us_per_step'] == 2.0 * (n - 1)
+  assert whole['gap_between_steps_us'] == 2.0 and classes['gemm_qkv']['avg_gap_before_us'] == 2.0
+  # a fused query projection (no cross-q launch, no merge launch): the attention after attention-out is the cross-attention
+  fused = [k for k in layer if 'EpiStoreH16' not in k and 'merge' not in k]
+  _write_trace(path, [g % ('32, 32, 4', 'EpiInProj<2>')] + fused * 2 + ['void msd::sampler_step_kernel<0>(msd::SamplerParams)'])
+  classes, steps, _ = bench.kernel_trace_classes(path)
+  assert steps == 1 and classes['attn_cross']['launches_per_step'] == 2 and classes['gemm_cross_out']['launches_per_step'] == 2
+  assert 'gemm_cross_q' not in classes and classes['gemm_mlp_out']['launches_per_step'] == 2
 
 
 def test_watchdog_exit_code_is_a_failure():

@@ -149,6 +149,40 @@ def test_attention(env, prec, tol, nq, nk, valid, heads):
       assert err < bound, (qp, err)
 
 
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+@pytest.mark.parametrize('nq,nk,valid,heads,ksplit', [(256, 2304, 2304, 12, 4), (256, 1408, 1356, 12, 4), (256, 768, 700, 12, 2),
+                                                      (64, 512, 301, 2, 2), (128, 1024, 1000, 3, 8), (64, 512, 130, 1, 4)])
+def test_attention_key_split_merged_inside_the_launch(env, prec, nq, nk, valid, heads, ksplit):
+  """Round 6: a key-split attention finishes INSIDE its launch -- every block publishes its partial write-through (sc1),
+  takes a ticket, the last block of a (query tile, head) group merges the partials (attention.h
+  attention_inlaunch_merge; MI355X guide G16 R1).  Against the separate merge launch the result must be BIT-identical
+  (one merge function), on the first launch and on the 25th back-to-back launch (the arrival counters reset
+  themselves; a stale partial from another XCD's L2 or a counter off by one would show here), at the decoder's own
+  shape (12 heads x 4 query tiles x 4 splits = 192 blocks) and on ragged / short key axes where some splits are empty;
+  and it must sit on the float64 oracle like the plain kernel."""
+  torch, native = env
+  from oracle import backend, ops
+  rng = np.random.default_rng(nq + nk + valid + ksplit)
+  j = heads * 64
+  q = (rng.standard_normal((nq, j)) * 0.35).astype(np.float32)
+  k = (rng.standard_normal((nk, j)) * 0.35).astype(np.float32)
+  v = rng.standard_normal((nk, j)).astype(np.float32)
+  qd, kd, vd = _dev(torch, q), _dev(torch, k), _dev(torch, v)
+  outs = {}
+  for name, inl, reps in (('merge launch', False, 1), ('in launch', True, 1), ('in launch x25', True, 25), ('merge launch x3', False, 3)):
+    o = torch.full((nq, j), float('nan'), dtype=torch.float32, device='cuda')
+    native.op_attention_split(prec, qd, kd, vd, o, heads, ksplit, inl, repeats=reps, n_keys_valid=valid)
+    outs[name] = o.cpu().numpy()
+  for name, got in outs.items():
+    assert np.isfinite(got).all(), name
+    assert np.array_equal(got, outs['merge launch']), (name, np.abs(got - outs['merge launch']).max())
+  xp = backend.NumpyBackend('float64')
+  sh = lambda x, n: x.reshape(1, n, heads, 64).astype(np.float64)
+  ref = ops.dot_product_attention(xp, sh(q, nq), sh(k[:valid], valid), sh(v[:valid], valid)).reshape(nq, j)
+  tol = 2e-5 if prec == 'f16x3' else 5e-3
+  assert np.abs(outs['in launch'] - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize('s_std', [3.5, 10.0, 20.0])
 def test_attention_sharp_logits_by_query_side_planes(env, s_std):
   """SHARP attention: logits with standard deviation `s_std` -- the top competing keys of a

@@ -14,6 +14,15 @@ first)
   timeout 600 python bench.py --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 600 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
   PRESET=small SKIP_TRACE=1 bash tools/profile_round.sh ${TAG}_small
   ;;
+second)  # in-launch merge of the key-split cross-attention: op-level and model-level bitwise tests, then in-process A/B
+  timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "merged_inside_the_launch or test_attention" > $OUT/${TAG}_op_tests.log 2>&1; tail -4 $OUT/${TAG}_op_tests.log
+  timeout 1200 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "draws_the_step_noise or staging or exact_launch or key_split or batched_songs or sum_cross" > $OUT/${TAG}_model_tests.log 2>&1; tail -4 $OUT/${TAG}_model_tests.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_merge_ab.json 'cross_merge_in_launch=False' 'cross_merge_in_launch=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_merge_ab.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --tokens 300 --tokens 1300 --json $OUT/${TAG}_merge_ab2.json 'cross_merge_in_launch=False' 'cross_merge_in_launch=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_merge_ab2.log
+  timeout 300 python tools/ab/knob_ab.py --preset small --rounds 4 --json $OUT/${TAG}_merge_ab_small.json 'cross_merge_in_launch=False' 'cross_merge_in_launch=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_merge_ab_small.log
+  mkdir -p $OUT/${TAG}_selfprof
+  timeout 600 python bench.py --no-cpu-baseline --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 300 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
+  ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
