@@ -35,7 +35,61 @@ classify = bench.classify_kernel
 step_kernel_names = bench.step_kernel_names
 
 
+def small_record(tag):
+  """BASELINE config 2 (`small`): profiles/<tag>_kernel_stats.csv (bench.py's own rocprofv3 leg, --self-profile-keep) +
+  profiles/<tag>_pmc_{fetch,write,sq}.csv (PRESET=small tools/profile_round.sh) + the bench line's position-based classes
+  (profiles/<bench json>: small.roofline.per_class_us) -> profiles/roofline_small.json.  In this model ONE residual-GEMM
+  instantiation serves attention-out, cross-out and MLP-out and one attention kernel both attentions, so the counter
+  passes (which aggregate by kernel NAME) are reported per instantiation, the durations per class."""
+  prof = os.path.join(ROOT, 'profiles')
+  stats_csv = os.path.join(prof, '%s_kernel_stats.csv' % tag)
+  step_kernels = step_kernel_names(stats_csv)
+  rows = {normalise(r['Name']): r for r in csv.DictReader(open(stats_csv))}
+  steps = max(int(r['Calls']) for n, r in rows.items() if 'sampler_step_kernel' in n)
+
+  def pmc(name):
+    path = os.path.join(prof, '%s_pmc_%s.csv' % (tag, name))
+    return {r['kernel']: r for r in csv.DictReader(open(path))} if os.path.exists(path) else {}
+  fetch, write, sq = pmc('fetch'), pmc('write'), pmc('sq')
+  per_kernel = {}
+  for k in sorted(step_kernels):
+    r = rows[k]
+    us = float(r['TotalDurationNs']) / int(r['Calls']) / 1e3
+    e = {'launches_per_step': round(int(r['Calls']) / steps, 3), 'avg_us': round(us, 3)}
+    if k in sq:
+      busy = float(sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'])
+      e['mfma_busy_cycles'] = busy
+      e['mfma_util'] = round(busy / (SIMDS * us * 1e-6 * CLOCK_GHZ * 1e9), 4)
+    if k in fetch:
+      fb = (2.0 * float(fetch[k]['FETCH_SIZE']) + float(write.get(k, {}).get('WRITE_SIZE', 0.0))) * 1024
+      e['fabric_bytes_per_launch'] = int(round(fb))
+      e['fabric_gbs'] = round(fb / (us * 1e-6) / 1e9, 1)
+    per_kernel[k] = e
+  doc = {'tag': tag, 'preset': 'small', 'library_sha': open(os.path.join(prof, '%s_library_sha.txt' % tag)).read().strip(),
+         'source': 'bench.py self_profile child (rocprofv3 --kernel-trace --stats, preset small) + PRESET=small tools/profile_round.sh '
+                   'counter passes (12 DDPM steps each; the encoder shares the step\'s PF = 0 instantiations, 8 launches in ~900)',
+         'assumptions': {'clock_ghz': CLOCK_GHZ, 'simds': SIMDS, 'peak_bf16_tflops': bench.PEAK_BF16_TFLOPS,
+                         'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 16 B/lane reads at half size); WRITE_SIZE as reported'},
+         'steps_traced': steps, 'per_kernel': per_kernel}
+  for cand in sorted(os.listdir(prof)):
+    if cand.startswith(tag.split('_')[0]) and cand.endswith('bench_default.json'):
+      line = json.load(open(os.path.join(prof, cand)))
+      rl = line.get('small', {}).get('roofline', {})
+      if rl.get('per_class_us'):
+        doc['per_class'] = rl['per_class_us']
+        doc['whole_step'] = rl.get('whole_step')
+        doc['dominant'] = {k: rl.get(k) for k in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch')}
+        doc['bench_line'] = 'profiles/' + cand
+  with open(os.path.join(prof, 'roofline_small.json'), 'w') as f:
+    json.dump(doc, f, indent=1)
+  for k, e in sorted(per_kernel.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['launches_per_step']):
+    print('%-70s x%-6s %7.2f us  mfma %s  fabric %s MB' % (k, e['launches_per_step'], e['avg_us'], e.get('mfma_util'),
+                                                            round(e.get('fabric_bytes_per_launch', 0) / 1e6, 2)))
+
+
 def main():
+  if len(sys.argv) > 2 and sys.argv[2] == '--small':
+    return small_record(sys.argv[1])
   tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
   s_valid = float(sys.argv[2]) if len(sys.argv) > 2 else 1100.0 + 256.0
   prof = os.path.join(ROOT, 'profiles')
