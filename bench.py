@@ -776,6 +776,12 @@ class Watchdog:
     return False
 
 
+def comm_device_of(args, model):
+  """Where the hand-off message lives: device memory under RCCL ('nccl'); the host under gloo (its point-to-point calls
+  take CPU tensors only) -- also when the MODEL is on a GPU (the -m gpu test of this launcher: two ranks, one device)."""
+  return model.device if args.dist_backend == 'nccl' else 'cpu'
+
+
 def handoff_leg(args, model, spec, dist, rank, world, song_tokens, ctx_shape):
   """BASELINE config 4 as a leg of the plain N > 1 line: the 10-minute workload (--handoff-segments, 118) as a
   wavefront of K = ceil(118 / N) songs x N segments (beam/evaluation.py:191-223 per song: segment k+1 conditions on
@@ -800,17 +806,23 @@ def handoff_leg(args, model, spec, dist, rank, world, song_tokens, ctx_shape):
   _sync(model.device)
   t0 = time.perf_counter()
   outs = sharding.chained_wavefront(timed_predict_sequence, songs, ctx_shape, rank, world,
-                                    comm_device=model.device, seed=100, return_torch=True)   # (song j: noise seed 100 + j)
+                                    comm_device=comm_device_of(args, model), seed=100, return_torch=True)   # (song j: noise seed 100 + j)
   _sync(model.device)
   mine = time.perf_counter() - t0
   dist.barrier()
   _sync(model.device)
   elapsed = time.perf_counter() - t0
   finite = all(bool(torch.isfinite(torch.as_tensor(o)).all()) for o in outs)
+  import hashlib
+  # what this rank synthesized, song by song, as a digest of the float32 bytes: a test (or a SCALE reader) can compare
+  # it with the sequential song's segment `rank` -- the hand-off is bit-identical by construction
+  digests = [hashlib.sha256(np.ascontiguousarray(torch.as_tensor(o).detach().cpu().numpy(), np.float32).tobytes()).hexdigest()[:16]
+             for o in outs]
   rows = [None] * world
   dist.all_gather_object(rows, {'rank': rank, 'seconds': round(mine, 4), 'busy_seconds': round(busy[0], 4),
-                                'idle_fraction': round(1.0 - busy[0] / max(elapsed, 1e-9), 4), 'finite': finite})
-  tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+                                'idle_fraction': round(1.0 - busy[0] / max(elapsed, 1e-9), 4), 'finite': finite,
+                                'segment_sha256_16': digests})
+  tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_device_of(args, model))
   dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
   elapsed = float(tmax.item())
   t_frames = spec.task_feature_lengths['targets']
@@ -968,11 +980,11 @@ def main():
   elif mode == 'chained':      # one song, world * K segments, rank r owns [r K, (r+1) K)
     song = [t[:1] for t in song_tokens(0, world * args.steps)]
     out = sharding.chained_predict(model.predict_sequence, song, ctx_shape, rank, world,
-                                   comm_device=model.device, return_torch=True)
+                                   comm_device=comm_device_of(args, model), return_torch=True)
   elif mode == 'wavefront':    # K songs of `world` segments: rank r runs segment r of every song
     songs = [[t[:1] for t in song_tokens(j, world)] for j in range(args.steps)]
     out = sharding.chained_wavefront(model.predict_sequence, songs, ctx_shape, rank, world,
-                                     comm_device=model.device, return_torch=True)[-1]
+                                     comm_device=comm_device_of(args, model), return_torch=True)[-1]
   else:                        # masked: chunk heads context-masked, no message
     song = [t[:1] for t in song_tokens(0, world * args.steps)]
     a, b = sharding.contiguous_chunk(len(song), rank, world)
@@ -987,7 +999,7 @@ def main():
   if dist is not None:
     per_rank_seconds = [None] * world
     dist.all_gather_object(per_rank_seconds, round(elapsed, 6))
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_device_of(args, model))
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   # the precision each rank ENDED in: range_fallback (on by default) switches a model to bfloat16 planes with a warning
@@ -1148,7 +1160,7 @@ def main():
         printed.append(1)
 
     with Watchdog(args.handoff_timeout, bail):
-      handoff = handoff_check(dist, rank, world, model.device, (1, c_len, 128))
+      handoff = handoff_check(dist, rank, world, comm_device_of(args, model), (1, c_len, 128))
       if rank == 0:
         result['handoff_check'] = handoff
       if mode == 'replicas' and args.handoff_segments > 0 and nb == 1:
