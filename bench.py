@@ -547,16 +547,31 @@ def cpu_config1(cores, cfg_weight):
 
 def probe_reference():
   """time the real JAX/T5X reference on the host cores if its stack is importable on
-  this box; otherwise the oracle port stands in (kind "port").  The probe result is reported either way."""
+  this box; otherwise the oracle port stands in (kind "port").  The probe result is reported either way.  When `jax`
+  alone imports, the N5 pin runs (tools/pin/pin_jax_random.py: this package's restated threefry + normal against
+  jax.random, bit for bit) and its verdict rides in the record."""
   missing = []
   for mod in ('jax', 'flax', 't5x', 'gin', 'seqio'):
     try:
       __import__(mod)
     except Exception:
       missing.append(mod)
+  pin = None
+  if 'jax' not in missing:
+    try:
+      import importlib.util
+      spec = importlib.util.spec_from_file_location('pin_jax_random', os.path.join(ROOT, 'tools', 'pin', 'pin_jax_random.py'))
+      mod = importlib.util.module_from_spec(spec)
+      spec.loader.exec_module(mod)
+      res = mod.compare(mod.JaxSide(), [0, 42], 4, [1, 256, 128])
+      pin = 'N5 pin (jax_random vs jax.random, 2 seeds x (init_z + 4 steps)): %s' % ('BIT-IDENTICAL' if res['ok'] else 'DIFFERS: %s' % json.dumps(res['cases'][0])[:300])
+    except Exception as e:
+      pin = 'N5 pin failed to run: %s' % repr(e)[:200]
   if missing:
-    return 'reference stack not importable here (missing: %s) -> oracle port timed instead' % ', '.join(missing)
-  return 'jax/flax/t5x importable, but the reference sources are not on this box (no /root/reference at run time)'
+    msg = 'reference stack not importable here (missing: %s) -> oracle port timed instead' % ', '.join(missing)
+  else:
+    msg = 'jax/flax/t5x importable, but the reference sources are not on this box (no /root/reference at run time)'
+  return msg if pin is None else msg + '; ' + pin
 
 
 def synthetic_midi_tokens(spec, seed, n_segments):
