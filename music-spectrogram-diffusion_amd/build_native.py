@@ -5,8 +5,8 @@ sources (music-spectrogram-diffusion_amd/csrc/libmsd_amd.so) so that it travels
 with the repository snapshot to the GPU box.  Two builds of the same sources:
 libmsd_amd.so (operand planes in IEEE half: precisions 'f16x3' / 'f16') and
 libmsd_amd_bf16.so (-DMSD_PLANE_BF16=1, bfloat16 planes: 'bf16x3' / 'bf16'; csrc/common.h).  The measured-and-rejected
-kernels of rounds 2 - 4 and their environment switches live OUTSIDE the product tree: tools/ubench/exp/src_r04 holds the
-sources they were built from (frozen, ABI 4) and ``build(experiments=True)`` / ``--experiments`` builds
+kernels of rounds 2 - 4 and their environment switches live OUTSIDE the product tree: tools/ubench/exp/src_r04 -- round 4's
+sources (ABI 4), rebuilt from history by tools/ubench/exp/restore_src_r04.sh, not kept in the tree -- and ``build(experiments=True)`` / ``--experiments`` builds
 tools/ubench/exp/libmsd_amd_exp.so from there, if that directory exists.  Nothing in csrc/ refers to it.
 ``python -m`` cannot name this package (dash), so run:  python music-spectrogram-diffusion_amd/build_native.py
 """
@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
   targets = [(lib, defs, CSRC) for lib, defs in LIBS.values()]
   if experiments:
     if not os.path.isdir(EXP_SRC):
-      raise RuntimeError('%s is missing: the experiments build needs the frozen round-4 sources' % EXP_SRC)
+      raise RuntimeError('%s is missing: run `bash tools/ubench/exp/restore_src_r04.sh` first (the experiments build needs round 4\'s sources)' % EXP_SRC)
     targets += [(lib, defs, EXP_SRC) for lib, defs in EXP_LIBS.values()]
   for lib, defs, src in targets:
     if not force and not needs_build(lib):

@@ -58,7 +58,7 @@ def test_phase_times_table_arithmetic():
 def test_product_library_reads_no_environment():
   """Every knob a caller may choose is a msd_config field; the product sources contain no getenv, no experiments /
   ablation conditional and no include that leaves csrc/ + include/ (round 5: the rejected kernels and their switches
-  are frozen under tools/ubench/exp/src_r04, a directory the product never names)."""
+  build from round 4's sources, which tools/ubench/exp/restore_src_r04.sh reconstructs from history -- a directory the product never names)."""
   import re
   for f in sorted(os.listdir(CSRC)):
     if not f.endswith(('.h', '.hip')):

@@ -2,7 +2,7 @@
 """One-off (round 5): remove the experiments / ablation conditionals from the product sources.
 
 `#if MSD_EXPERIMENTS` is evaluated as 0, `#if defined(MSD_DMA_ABL) && ...` as 0; every other conditional is kept.
-The sources as they were (with the experiments) are frozen under tools/ubench/exp/src_r04/.
+The sources as they were (with the experiments): tools/ubench/exp/restore_src_r04.sh rebuilds tools/ubench/exp/src_r04/ from history.
 usage: strip_experiments.py FILE...   (rewrites in place)
 """
 import re
