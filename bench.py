@@ -776,11 +776,15 @@ class Watchdog:
   EXIT_CODE = 3   # a hang is a FAILURE of the run: the line is still printed (with its error field), the exit code says so
 
   def _fire(self):
+    # Only RANK 0 leaves with the failure code, and only after it has printed: torch.distributed.run answers the first
+    # failed worker by sending SIGTERM to all the others -- a rank > 0 that timed out a moment earlier and left non-zero
+    # took rank 0 down before it could print (the line was lost in one run of three).  The launcher's exit code is
+    # non-zero as soon as one worker's is.
     try:
       self.on_timeout(self.seconds)
     finally:
       sys.stdout.flush()
-      os._exit(self.EXIT_CODE)
+      os._exit(self.EXIT_CODE if int(os.environ.get('RANK', '0')) == 0 else 0)
 
   def __enter__(self):
     self.t.start()
