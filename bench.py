@@ -513,11 +513,47 @@ def cpu_baseline(spec, params, batch, sample_steps: int, budget_s: float = 20.0)
   return {
       'value': t / seg_s, 'unit': 'mel-frames/sec', 'cores': cores, 'kind': 'port', 'reference_probe': probe_reference(),
       'config1': cpu_config1(cores, w),
+      'as_written': cpu_as_written(spec, params, batch, cores, t_step),
       'xRTF': (t * 320 / 16000.0) / seg_s,
       'sample': 'torch-CPU float32 oracle (oracle/fast.py, cached cross K/V): encoders %.2fs + %d of %d '
                 'DDPM steps at %.3fs/step, extrapolated linearly to one %d-frame segment'
                 % (t_enc, sample_steps, n_full, t_step, t),
   }
+
+
+def cpu_as_written(spec, params, batch, cores, fast_step_s, steps=2):
+  """The reference path AS WRITTEN on the host cores, beside the shortcut model the main figure times: oracle/predict.py
+  restates predict_batch_with_aux line by line -- both encoders, then per DDPM step two full decoder calls that
+  RE-PROJECT the cross-attention K / V of all 2304 positions and evaluate the time-embedding MLP and all FiLM layers
+  (models/diffusion/network.py:196-235, 377-392) -- which oracle/fast.py (and the device) hoist out of the loop.  Timed on
+  a `steps`-step schedule (the per-step cost does not depend on the step count) and extrapolated like the main figure."""
+  import msd_amd
+  from oracle import backend, predict
+  from tests import helpers
+  n_full = spec.diffusion.sampler.schedule.num_steps
+  short = msd_amd.config.preset('base_with_context' if spec.has_context else 'small', num_steps=steps,
+                                cfg_weight=spec.diffusion.classifier_free_guidance.eval_condition_weight)
+  if short.t5 != spec.t5:
+    return {'skipped': 'not a shipped preset'}
+  xp = backend.TorchBackend('float32', threads=cores)
+  cfg, dc = helpers.oracle_configs(short)
+  init_z, noise = helpers.make_noise(short)
+  t0 = time.perf_counter()
+  predict.predict_batch_with_aux(xp, cfg, dc, params, batch, init_z, noise, context=spec.has_context)
+  dt = time.perf_counter() - t0
+  cfg0, dc0 = helpers.oracle_configs(msd_amd.config.preset('base_with_context' if spec.has_context else 'small', num_steps=1,
+                                                            cfg_weight=spec.diffusion.classifier_free_guidance.eval_condition_weight))
+  z1, n1 = helpers.make_noise(msd_amd.config.preset('base_with_context' if spec.has_context else 'small', num_steps=1))
+  t0 = time.perf_counter()
+  predict.predict_batch_with_aux(xp, cfg0, dc0, params, batch, z1, n1, context=spec.has_context)
+  dt1 = time.perf_counter() - t0
+  step_s = max(dt - dt1, 1e-9) / (steps - 1)          # (encoders + one step) subtracted: what one more step costs
+  seg_s = (dt1 - step_s) + n_full * step_s
+  t = spec.task_feature_lengths['targets']
+  return {'value': round(t / seg_s, 4), 'unit': 'mel-frames/sec', 'xRTF': round((t * 320 / 16000.0) / seg_s, 5), 'cores': cores,
+          'kind': 'port', 'seconds_per_step': round(step_s, 4), 'ratio_to_shortcut_model_step': round(step_s / fast_step_s, 3),
+          'sample': 'oracle/predict.py (the reference path as written: K / V re-projected, time MLP + FiLM evaluated in every '
+                    'decoder call): a %d-step and a 1-step run, their difference = one step, extrapolated to %d steps' % (steps, n_full)}
 
 
 def cpu_config1(cores, cfg_weight):
