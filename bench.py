@@ -397,6 +397,8 @@ def self_profile(args, preset, timeout_s=300.0, keep_csv=None):
          '--steps', str(n_timed), '--data', args.data]
   if args.attn_planes:
     cmd += ['--attn-planes', args.attn_planes]
+  for item in (args.knob or []):
+    cmd += ['--knob', item]
   env = dict(os.environ)
   env['TMPDIR'] = '/tmp'
   t0 = time.perf_counter()
@@ -898,6 +900,10 @@ def model_kwargs(args):
   if args.attn_planes:
     q, p = (int(v) for v in args.attn_planes.split(','))
     kw['attention_query_planes'] = (q, p)
+  for item in (args.knob or []):   # e.g. --knob cross_q_fold=False: an InferenceModel keyword (launch-level A/B on one box)
+    import ast
+    k, v = item.split('=', 1)
+    kw[k.strip()] = ast.literal_eval(v.strip())
   return kw
 
 
@@ -915,6 +921,8 @@ def main():
   ap.add_argument('--num-steps', type=int, default=1000, help='DDPM steps (headline: 1000)')
   ap.add_argument('--cfg-weight', type=float, default=5.0)
   ap.add_argument('--batch', type=int, default=1, help='independent songs synthesized together per GPU')
+  ap.add_argument('--knob', action='append', default=None, help='k=v: an InferenceModel keyword that is not the library '
+                  'default (e.g. cross_q_fold=False), for launch-level A/Bs; named in config.knobs')
   ap.add_argument('--attn-planes', default='', help='q,p planes of the query side of the decoder attentions (e.g. "1,1" = '
                   "round 3's single plane); default: the library's choice (hi + lo for both: DESIGN.md 3)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -1177,7 +1185,8 @@ def main():
                                   else 'independent segments (no context), one after the other',
                                   args.steps, t_frames),
                    'precision': precision_ran, 'precision_requested': args.precision, 'parallelism': par, 'mode': mode,
-                   'attention_query_planes': args.attn_planes or 'library default: hi + lo for Q and for the softmax weights'},
+                   'attention_query_planes': args.attn_planes or 'library default: hi + lo for Q and for the softmax weights',
+                   'knobs': args.knob or 'library defaults'},
         'roofline': roofline,
     }
     if mode == 'replicas':

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 6   /* 6: cross_merge_in_launch, cross_q_in_attention appended to msd_config.
+#define MSD_AMD_ABI_VERSION 6   /* 6: cross_merge_in_launch, cross_q_fold appended to msd_config.
                                    5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
                                    4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
@@ -183,10 +183,14 @@ typedef struct msd_config {
                                      partial write-through, the last block of a (query tile, head) group to arrive merges
                                      them -- no separate merge launch (one kernel boundary less per decoder layer);
                                      bit-identical to the merge launch.  0 = the library's choice (on), 1 = on, 2 = off */
-  int32_t cross_q_in_attention;   /* the cross-attention's query projection runs inside the attention launch (each block
-                                     projects its own 64 x 64 query tile from the normed rows while its first K / V
-                                     stage lands) instead of as a GEMM launch of its own; bit-identical.  0 = the
-                                     library's choice, 1 = on, 2 = off */
+  int32_t cross_q_fold;           /* the cross-attention's query projection has no launch of its own (one kernel boundary
+                                     less per decoder layer).  Exact algebra on network.py:174-198: with x1 = x0 + ao . Wo,
+                                     (x1 (.) gamma) . Wq = (x0 (.) gamma) . Wq + ao . (Wo diag(gamma) Wq) -- the first term
+                                     rides on the QKV launch's idle CUs, the second runs beside the self-attention output
+                                     projection (same A operand), and the 1/rms of the norm moves onto the logits inside
+                                     the attention kernel.  Same float32-class result, NOT bit-identical to the unfolded
+                                     order (3e-7 relative on a decoder pass).  Two-plane precisions, up to 3 songs per
+                                     call.  0 = the library's choice (on), 1 = on, 2 = off */
 } msd_config;
 
 const char* msd_version(void);

@@ -63,6 +63,12 @@ struct AttnParams {
   int* tickets = nullptr;    // ksplit > 1, in-launch merge (round 6, attention_inlaunch_merge below): one arrival counter per
                              // (segment, query block of this launch, head), all zero between launches; nullptr = the
                              // separate attention_merge_kernel launch finishes the split
+  // UN-NORMALISED queries (the folded cross-attention query projection, gemm_h16.h): `q` holds (x (.) gamma) . Wq without
+  // the 1/rms of the pre-attention RMSNorm; the kernel scales the logits of query row r by
+  // rstd[r] = rsqrt(sum_t q_ssq[r][t] * q_inv_d + 1e-6) -- the algebra of the GEMMs' folded norms (QP bit 2)
+  const float* q_ssq = nullptr;   // [rows][q_tiles] partial sums of squares of the residual stream
+  int q_tiles = 0;                // <= kAuxMaxTiles
+  float q_inv_d = 0.f;
 };
 
 typedef __attribute__((ext_vector_type(8))) plane_elem frag8;
@@ -88,8 +94,10 @@ constexpr int attention_work_smem() {
              ? NS * NP * (kAttKBytes + kAttVBytes) + QB * NP * kAttQBytes
              : QB * kAttKG * kAttWStride * 4;
 }
-template <int NP, int NS, int QB>
-constexpr int attention_smem() { return attention_work_smem<NP, NS, QB>() + (QB < 4 ? kAttTouchSink : 0); }   // (QB = 4: the 160 KiB are full; no prefetch wave there)
+// (QS: the launches with un-normalised queries also stage the block's rows of q_ssq -- QB x 32 rows x kAuxMaxTiles floats)
+constexpr int kAttSsqBytes = 32 * kAuxMaxTiles * 4;   // per query block
+template <int NP, int NS, int QB, bool QS = false>
+constexpr int attention_smem() { return attention_work_smem<NP, NS, QB>() + (QB < 4 ? kAttTouchSink : 0) + (QS ? QB * kAttSsqBytes : 0); }   // (QB = 4: the 160 KiB are full; no prefetch wave there)
 
 // Query blocks per workgroup for a launch of `blocks64` 64-row blocks (heads x query tiles x key splits x segments):
 //   < 128 blocks           -> 32-row blocks (QB = 1): twice as many, when most of the 256 CUs would be idle
@@ -179,6 +187,7 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
 template <int KS>
 __device__ __forceinline__ void merge_split_partials(const f32x2 (&ml)[KS], const f32x4 (&oa)[KS], const f32x4 (&ob)[KS],
                                                      float (&v)[8]) {
+#pragma clang fp contract(off)   // (see attention_kernel)
   float mt = -1e30f, lt = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -187,9 +196,9 @@ __device__ __forceinline__ void merge_split_partials(const f32x2 (&ml)[KS], cons
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const float f = fast_exp(ml[ks][0] - mt);
-    lt += ml[ks][1] * f;
+    lt = __builtin_fmaf(ml[ks][1], f, lt);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { acc[e] += oa[ks][e] * f; acc[4 + e] += ob[ks][e] * f; }
+    for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(oa[ks][e], f, acc[e]); acc[4 + e] = __builtin_fmaf(ob[ks][e], f, acc[4 + e]); }
   }
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
 #pragma unroll
@@ -261,8 +270,14 @@ __device__ __forceinline__ void attention_inlaunch_merge(const AttnParams& p, in
 // QP: query-side single-plane switches of the NP = 2 modes (bit 0: Q enters S = K.Q^T as ONE plane, bit 1: P enters
 // O += V^T.P^T as one plane): 2 instead of 3 MFMAs for that product, and no hi / lo split of P.  The memory side
 // (K, V) always keeps both planes (dropping those costs 20 - 50x the error).  0 = all three products.
+// Bit 2 (QS): the queries are un-normalised, see AttnParams::q_ssq.
 template <int NP, int NS, int QB, int PF = kPfNone, int QP = 0>
 __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNone ? 64 : 0)) attention_kernel(AttnParams p) {
+  // Every multiply-add of this kernel that is MEANT to be fused is an explicit fma, and nothing else may be: left to
+  // -ffp-contract=fast the instantiations contracted differently (round 6: <QB = 2, PF = 1> fused four packed
+  // multiply-adds fewer than <QB = 1, PF = 1> and the PF = 0 pair -- the last bit of a segment then depended on which
+  // block shape the launcher picked, e.g. on dedup_layer0 at two songs: tools/diag/bitwise_matrix.py)
+#pragma clang fp contract(off)
   static_assert(QB < 4 || PF == kPfNone, "16 compute waves fill the workgroup: no prefetch wave");
   warm_kernargs<kernarg_lines<AttnParams>()>();
   if constexpr (kPfWaveAttn && PF != kPfNone) {
@@ -277,7 +292,8 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       return;
     }
   }
-  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2);
+  constexpr bool Q1 = NP == 2 && (QP & 1), P1 = NP == 2 && (QP & 2), QS = (QP & 4) != 0;
+  static_assert(!QS || QB < 4, "un-normalised queries: 32- and 64-row blocks only (the 128-row block fills the LDS)");
 #if MSD_TIMESTAMPS
   const int ts_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   constexpr int ts_cls = QB == 1 ? 4 : 5;
@@ -346,6 +362,20 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
   const size_t qrow = qrow0 + q_lane;
   constexpr int NPQ = Q1 ? 1 : NP;                     // planes of Q the products use
   constexpr int QOFF = NS * STAGE;
+  // QS: the partial sums of squares of the block's query rows (kRows x q_tiles floats, contiguous) -> LDS behind the
+  // touch sink, by LDS-DMA like the Q tile and in front of it: the oldest operations of every wave's vmcnt queue, so
+  // the counted wait of stage 0 covers them.  (Round 3's hoist read them with ordinary loads into registers: beside
+  // LDS-DMA that is a vmcnt(0) at their first use -- the cross-attention launch grew by 1.7 us, docs/history.md.)
+  constexpr int SSQOFF = attention_work_smem<NP, NS, QB>() + kAttTouchSink;
+  if constexpr (QS) {
+    const int bytes = kRows * p.q_tiles * 4;
+    if (wave * 1024 < bytes) {   // at most one 1 KiB instruction per wave (q_tiles <= kAuxMaxTiles)
+      int off = wave * 1024 + lane * 16;
+      off = off < bytes - 16 ? off : bytes - 16;
+      const char* src = reinterpret_cast<const char*>(p.q_ssq + ((size_t)seg * p.q_rows_per_seg + blk * kRows) * p.q_tiles) + off;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + SSQOFF + wave * 1024), 16, 0, 0);
+    }
+  }
 #pragma unroll
   for (int pl = 0; pl < NPQ; ++pl)   // wave (qb, kg) moves rows 8 kg .. 8 kg + 7 of its query block, every plane
     __builtin_amdgcn_global_load_lds(
@@ -379,9 +409,12 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = NEG, l_run = 0.f;
+  float rq = 1.f;   // QS: 1/rms of this lane's query row
 
   int buf = 0;
-  for (int st = 0; st < nst; ++st) {
+  // one stage of the key loop.  A lambda so that the QS form can PEEL stage 0 in the source (below); the plain form calls
+  // it from the loop it always was.
+  auto stage = [&](const int st) __attribute__((always_inline)) {
     // stage st must have landed.  Issued so far: stages 0 .. st+NS-2 (0 .. NS-1 at st = 0).
     if (st == 0) {   // NS stages were issued, whatever nst is
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");
@@ -399,6 +432,21 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
         for (int s4 = 0; s4 < 4; ++s4)
           qf[pl][s4] = *reinterpret_cast<const frag8*>(smem + QOFF + (qb * NP + pl) * kAttQBytes + q_lane * 128 +
                                                        (((2 * s4 + hi) ^ (q_lane & 7)) << 4));
+      if constexpr (QS) {   // all reads issued together (fixed trip count, clamped index, zero for the tail); q_tiles % 4 == 0
+        typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_t;
+        lds_f32x4_t sp = (lds_f32x4_t)(size_t)(unsigned)(size_t)(smem + SSQOFF + (qb * 32 + q_lane) * p.q_tiles * 4);
+        const int n4 = p.q_tiles >> 2;
+        f32x4 sv[kAuxMaxTiles / 4];
+#pragma unroll
+        for (int t = 0; t < kAuxMaxTiles / 4; ++t) sv[t] = sp[t < n4 ? t : 0];
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < kAuxMaxTiles / 4; ++t) {
+          const float g4 = (sv[t][0] + sv[t][1]) + (sv[t][2] + sv[t][3]);
+          acc += t < n4 ? g4 : 0.f;
+        }
+        rq = 1.0f / sqrtf(__builtin_fmaf(acc, p.q_inv_d, 1e-6f));
+      }
     }
 #if MSD_TIMESTAMPS
     if (st == 0) { MSD_TS_AT(ts_cls, ts_blk, 2) }
@@ -437,6 +485,10 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) MSD_A_ISSUE(st + NS - 1, nb)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= rq;
+      }
       // lane owns keys kb0 + (r&3) + 8*(r>>2) + 4*hi for r = 0..15
       float bmax = NEG;
       if (kb0 + 32 > nkeys) {  // only the last, ragged key block needs the bound
@@ -458,7 +510,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
         pv[r] = fast_exp(s[r] - m_new);
         psum += pv[r];
       }
-      l_run = l_run * alpha + psum;
+      l_run = __builtin_fmaf(l_run, alpha, psum);
       m_run = m_new;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
@@ -500,6 +552,15 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
       }
     }
     buf = (buf + 1 == NS) ? 0 : buf + 1;
+  };
+  if constexpr (QS) {
+    // stage 0 peeled in the source: it alone reads the Q fragments and the row statistics, and left inside the loop those
+    // reads keep the compiler from peeling it by itself as it does for the plain form -- the QS launch then ran 2.4 us
+    // longer than the plain one on the same keys (profiles/r06c_*: 17.35 against 14.93 us)
+    if (nst > 0) stage(0);
+    for (int st = 1; st < nst; ++st) stage(st);
+  } else {
+    for (int st = 0; st < nst; ++st) stage(st);
   }
 #undef MSD_A_ISSUE
   // full-row sum: combine the two half-lanes that share a query
@@ -547,11 +608,13 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
     for (int w = 0; w < kAttKG; ++w) {
       const float* ws = wbase + w * kAttWStride;
       const float f = fast_exp(ws[32 * kAttOLD + q] - mt);
-      lt += ws[32 * kAttOLD + 32 + q] * f;
+      lt = __builtin_fmaf(ws[32 * kAttOLD + 32 + q], f, lt);
       const float4 a = *reinterpret_cast<const float4*>(ws + q * kAttOLD + d0);
       const float4 b = *reinterpret_cast<const float4*>(ws + q * kAttOLD + d0 + 4);
-      acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
-      acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
+      acc[0] = __builtin_fmaf(a.x, f, acc[0]); acc[1] = __builtin_fmaf(a.y, f, acc[1]);
+      acc[2] = __builtin_fmaf(a.z, f, acc[2]); acc[3] = __builtin_fmaf(a.w, f, acc[3]);
+      acc[4] = __builtin_fmaf(b.x, f, acc[4]); acc[5] = __builtin_fmaf(b.y, f, acc[5]);
+      acc[6] = __builtin_fmaf(b.z, f, acc[6]); acc[7] = __builtin_fmaf(b.w, f, acc[7]);
     }
     const size_t row = (size_t)seg * p.q_rows_per_seg + blk * kRows + mqb * 32 + q;
     if (p.ksplit == 1) {
@@ -594,6 +657,7 @@ __global__ void __launch_bounds__(QB * kAttKG * 64 + (kPfWaveAttn && PF != kPfNo
 // of every split are in flight together before anything is computed; the sums still run in split order (same bits).
 template <int NP, int KS = 0>
 __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int heads, unsigned inv_heads) {
+#pragma clang fp contract(off)   // (see attention_kernel)
   warm_kernargs<kernarg_lines<AttnParams, int, unsigned>()>();
   const int item = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d group)
   // row = (item / 8) / heads through the host's ceil(2^32 / heads) (exact while (item / 8) * heads < 2^32), no software division
@@ -623,11 +687,13 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
     for (int ks = 0; ks < p.ksplit; ++ks) {
       const size_t base = ((size_t)ks * p.total_rows + row) * heads + head;
       const float f = fast_exp(p.part_ml[base * 2] - mt);
-      lt += p.part_ml[base * 2 + 1] * f;
+      lt = __builtin_fmaf(p.part_ml[base * 2 + 1], f, lt);
       const float4 a = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0);
       const float4 b = *reinterpret_cast<const float4*>(p.part_o + base * 64 + d0 + 4);
-      acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
-      acc[4] += b.x * f; acc[5] += b.y * f; acc[6] += b.z * f; acc[7] += b.w * f;
+      acc[0] = __builtin_fmaf(a.x, f, acc[0]); acc[1] = __builtin_fmaf(a.y, f, acc[1]);
+      acc[2] = __builtin_fmaf(a.z, f, acc[2]); acc[3] = __builtin_fmaf(a.w, f, acc[3]);
+      acc[4] = __builtin_fmaf(b.x, f, acc[4]); acc[5] = __builtin_fmaf(b.y, f, acc[5]);
+      acc[6] = __builtin_fmaf(b.z, f, acc[6]); acc[7] = __builtin_fmaf(b.w, f, acc[7]);
     }
     const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
 #pragma unroll
@@ -642,7 +708,7 @@ __global__ void __launch_bounds__(256) attention_merge_kernel(AttnParams p, int 
 
 template <int NP, int NS, int QB, int QP>
 inline hipError_t attention_prepare_one() {
-  constexpr int smem = attention_smem<NP, NS, QB>();
+  constexpr int smem = attention_smem<NP, NS, QB, (QP & 4) != 0>();
   if (smem < 64 * 1024) return hipSuccess;
   const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NP, NS, QB, kPfNone, QP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -665,6 +731,8 @@ inline hipError_t attention_prepare() {
   if constexpr (NP == 2) {
     MSD_ATT_PREP(1, 1) MSD_ATT_PREP(2, 1) MSD_ATT_PREP(1, 2) MSD_ATT_PREP(2, 2) MSD_ATT_PREP(1, 3) MSD_ATT_PREP(2, 3)
     MSD_ATT_PREP(4, 0) MSD_ATT_PREP(4, 1) MSD_ATT_PREP(4, 2) MSD_ATT_PREP(4, 3)
+    MSD_ATT_PREP(1, 4) MSD_ATT_PREP(2, 4) MSD_ATT_PREP(1, 5) MSD_ATT_PREP(2, 5) MSD_ATT_PREP(1, 6) MSD_ATT_PREP(2, 6)
+    MSD_ATT_PREP(1, 7) MSD_ATT_PREP(2, 7)
   }
 #undef MSD_ATT_PREP
   return e;
@@ -676,13 +744,14 @@ inline void launch_attention_qp(const AttnParams& p, int heads, int segs, hipStr
   // 64-row blocks share K/V between two query blocks; when that leaves most of the 256 CUs without
   // a block, 32-row blocks (twice as many) finish sooner
   const int blocks64 = heads * (p.q_rows_per_seg / 64) * p.ksplit * segs;
-  constexpr int smem1 = attention_smem<NP, NS, 1>(), smem2 = attention_smem<NP, NS, 2>();
+  constexpr bool QS = (QP & 4) != 0;
+  constexpr int smem1 = attention_smem<NP, NS, 1, QS>(), smem2 = attention_smem<NP, NS, 2, QS>();
   // one instantiation per prefetch kind (gemm_h16.h); the single-plane mode never prefetches
   constexpr int PFW = NP == 2 ? 1 : 0;   // attention launches carry at most one target
   const bool pfw = NP == 2 && prefetch_kind(p.pf) >= 1;
   const dim3 g1(heads, (p.q_rows_per_seg / 32) * p.ksplit, segs), g2(heads, (p.q_rows_per_seg / 64) * p.ksplit, segs);
-  const int qb = attention_query_blocks(p.allow_qb4 ? blocks64 : (blocks64 > 256 ? 256 : blocks64), p.q_rows_per_seg, NP);
-  if constexpr (NP == 2) {
+  const int qb = attention_query_blocks((p.allow_qb4 && !QS) ? blocks64 : (blocks64 > 256 ? 256 : blocks64), p.q_rows_per_seg, NP);
+  if constexpr (NP == 2 && !QS) {
     if (qb == 4) {   // (no prefetch wave: the caller moved the launch's weight target elsewhere -- msd_api.hip)
       const dim3 g4(heads, (p.q_rows_per_seg / 128) * p.ksplit, segs);
       hipLaunchKernelGGL((attention_kernel<NP, NS, 4, kPfNone, QP>), g4, dim3(4 * kAttKG * 64), (attention_smem<NP, NS, 4>()), stream, p);
@@ -708,10 +777,15 @@ inline hipError_t launch_attention(const AttnParams& p_in, int heads, int segs, 
   while ((2 << p.ksplit_log2) <= p.ksplit) ++p.ksplit_log2;
   p.ksplit = 1 << p.ksplit_log2;   // a power of two (a request for 3 runs as 2): the kernel shifts, it never divides
   if constexpr (NP == 2) {
-    switch (p.qp & 3) {
+    if (p.q_ssq != nullptr && (p.q_tiles <= 0 || p.q_tiles > kAuxMaxTiles || p.q_tiles % 4)) return hipErrorInvalidValue;
+    switch ((p.qp & 3) | (p.q_ssq != nullptr ? 4 : 0)) {
       case 1: launch_attention_qp<NP, 1>(p, heads, segs, stream); break;
       case 2: launch_attention_qp<NP, 2>(p, heads, segs, stream); break;
       case 3: launch_attention_qp<NP, 3>(p, heads, segs, stream); break;
+      case 4: launch_attention_qp<NP, 4>(p, heads, segs, stream); break;
+      case 5: launch_attention_qp<NP, 5>(p, heads, segs, stream); break;
+      case 6: launch_attention_qp<NP, 6>(p, heads, segs, stream); break;
+      case 7: launch_attention_qp<NP, 7>(p, heads, segs, stream); break;
       default: launch_attention_qp<NP, 0>(p, heads, segs, stream); break;
     }
   } else {

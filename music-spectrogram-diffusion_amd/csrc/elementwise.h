@@ -334,6 +334,17 @@ __global__ void pack_wt_kernel(const float* w, int K, int N, h16_t* hi, h16_t* l
   if (lo) lo[(size_t)dst * ld + k0 + k] = l;
 }
 
+// out[k][n] = sum_d a[k][d] g[d] b[d][n]   (a: [K, D], b: [D, N], all fp32 row-major), accumulated in float64 and rounded
+// once: Wo_self . diag(gamma_cross) . Wq of the folded cross-attention query projection (msd_api.hip, load time).
+// block (16, 16): thread = (n, k)
+__global__ void fold_wq_kernel(const float* a, const float* g, const float* b, float* out, int K, int D, int N) {
+  const int n = blockIdx.x * 16 + threadIdx.x, k = blockIdx.y * 16 + threadIdx.y;
+  if (n >= N || k >= K) return;
+  double acc = 0.0;
+  for (int d = 0; d < D; ++d) acc += (double)a[(size_t)k * D + d] * (double)g[d] * (double)b[(size_t)d * N + n];
+  out[(size_t)k * N + n] = (float)acc;
+}
+
 // token embedding (one-hot contraction == row gather, layers.py:556-559) + position
 // table rows (network.py:278-287) for the valid positions of one sequence.
 //   x[r] = tok_emb[tokens[pos[r]]] + pos_emb[pos[r]]   r < n_valid ; 0 for padding rows

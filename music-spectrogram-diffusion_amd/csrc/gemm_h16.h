@@ -493,6 +493,28 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   prefetch_done(pf_keep);
 }
 
+// XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
+// and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
+// The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
+// With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
+// bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
+// traffic when the activations are as large as the weights (N = D projections).
+// (the divisions are the launcher's: GemmParams::TileMap).  `b`: index of the block among its problem's blocks.
+__device__ __forceinline__ bool gemm_block_tile(const GemmParams& p, int b, int& bm, int& bn) {
+  const GemmParams::TileMap& tm = p.map;
+  const int RX = p.xcd_rows, CX = 1 << tm.cx_log2;
+  const int xcd = b & 7, tt = b >> 3;
+  const int xr = xcd >> tm.cx_log2, xc = xcd & (CX - 1);
+  if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
+    const int q = tm.nbn_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbn_x) : tt;   // tt / nbn_x
+    bm = q * RX + xr; bn = (tt - q * tm.nbn_x) * CX + xc;
+  } else {              // row tiles fastest (a weight slice stays hot)
+    const int q = tm.nbm_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbm_x) : tt;   // tt / nbm_x
+    bm = (tt - q * tm.nbm_x) * RX + xr; bn = q * CX + xc;
+  }
+  return bn < tm.nbn && bm < tm.nbm;
+}
+
 constexpr int pf_threads(int pf) { return kPfWave && pf != kPfNone ? 64 : 0; }   // the prefetch wave of a launch, if any
 
 template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
@@ -505,26 +527,8 @@ __global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dma_kernel(Gemm
       return;
     }
   }
-  // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
-  // and walks their BM-blocks consecutively, so each weight slice is filled into ONE L2.
-  // The grid is 8 * ceil(nbn / 8) * nbm; blocks past the last column tile exit.
-  // With xcd_rows = RX > 1 the XCDs also split the M-blocks (XCD (xr, xc) owns bm = xr mod RX,
-  // bn = xc mod 8/RX): every L2 then fetches A/RX + B*RX/8 instead of A + B/8 -- less fabric
-  // traffic when the activations are as large as the weights (N = D projections).
-  // (the divisions are the launcher's: GemmParams::TileMap)
-  const GemmParams::TileMap& tm = p.map;
-  const int RX = p.xcd_rows, CX = 1 << tm.cx_log2;
-  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
-  const int xr = xcd >> tm.cx_log2, xc = xcd & (CX - 1);
   int bm, bn;
-  if (p.xcd_walk_n) {   // column tiles fastest inside an XCD (activation rows stay hot)
-    const int q = tm.nbn_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbn_x) : tt;   // tt / nbn_x
-    bm = q * RX + xr; bn = (tt - q * tm.nbn_x) * CX + xc;
-  } else {              // row tiles fastest (a weight slice stays hot)
-    const int q = tm.nbm_x > 1 ? (int)__umulhi((unsigned)tt, tm.inv_nbm_x) : tt;   // tt / nbm_x
-    bm = (tt - q * tm.nbm_x) * RX + xr; bn = q * CX + xc;
-  }
-  if (bn >= tm.nbn || bm >= tm.nbm) return;
+  if (!gemm_block_tile(p, (int)blockIdx.x, bm, bn)) return;
   gemm_tile<NP, BM, BN, NS, Epi, PF>(p, epi, bm, bn, smem);
 }
 
@@ -893,7 +897,10 @@ __device__ __forceinline__ void gain8(const float (&v)[8], float4 g0, float4 g1,
 // ALSO written as row r + dup_rows -- the unconditional pass starts from the same z, the same FiLM and the same
 // self-attention (models/diffusion/models.py:373-386, network.py:174-193), so up to here its rows are bit-for-bit the
 // conditional ones: x and ssq are copied, y[r] = x (.) g_lo and y[r + dup_rows] = x (.) g_hi (split_row is not used).
-template <int NP, bool DUP = false>
+// Y2 (the folded cross-attention query projection, msd_api.hip decoder_layers / DESIGN.md 5 S6): rows < y2_rows are ALSO
+// written as y2 = x (.) g2 -- g2 = the next cross-attention norm's plain scale, not step-indexed -- the A operand of the
+// half of that projection which does not wait for the self-attention block (narrow tiles only).
+template <int NP, bool DUP = false, bool Y2 = false>
 struct EpiResidualNorm {
   float* x;
   int ldx;
@@ -905,9 +912,12 @@ struct EpiResidualNorm {
   int split_row;
   const int* step_ptr;
   int dup_rows = 0;   // DUP only: distance to the second copy of a row (= rows of one pass)
-  // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB]
+  h16_t* y2[2] = {nullptr, nullptr};   // Y2 only
+  const float* g2 = nullptr;
+  int y2_rows = 0;
+  // aux layout (BN == 32 or 48): [x tile BM x BN fp32][g_lo slice, 1 KiB][g_hi slice, 1 KiB][Y2: g2 slice, 1 KiB]
   template <int BN> static constexpr bool narrow() { return BN == 32 || BN == 48; }
-  template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 2048 : 0; }
+  template <int BM, int BN> static constexpr int aux_bytes() { return narrow<BN>() ? BM * BN * 4 + 2048 + (Y2 ? 1024 : 0) : 0; }
   template <int BM, int LD>
   __device__ void stats(float*, int, int, const char*) const {}
   template <int BM, int BN>
@@ -925,6 +935,9 @@ struct EpiResidualNorm {
     // (only the two waves that fetch a step-indexed row read the scan index)
     if (g_lo && wave == 2) aux_dma_row(g_lo + (size_t)scan_index(step_ptr) * g_lo_stride + n0, aux + BM * BN * 4, BN * 4, lane);
     if (g_hi && wave == 3) aux_dma_row(g_hi + (size_t)scan_index(step_ptr) * g_hi_stride + n0, aux + BM * BN * 4 + 1024, BN * 4, lane);
+    if constexpr (Y2) {
+      if (g2 && wave == 1) aux_dma_row(g2 + n0, aux + BM * BN * 4 + 2048, BN * 4, lane);
+    }
   }
   // 32 x 48 tiles: 8 lanes per row, 6 of them with 8 columns each; ONE partial sum of squares per row and tile, in
   // slot n0 / 48 of the row's `tiles` (= D / 32) slots -- the D / 48 slots a row gets this way are fewer than `tiles`,
@@ -970,6 +983,15 @@ struct EpiResidualNorm {
       gain8(v, make_float4(g0[0], g0[1], g0[2], g0[3]), make_float4(g1[0], g1[1], g1[2], g1[3]), w);
       store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
     }
+    if constexpr (Y2) {
+      if (act && g2 != nullptr && row < y2_rows) {
+        lds_cf32x4 gc = (lds_cf32x4)(aux + BM * BN * 4 + 2048);
+        const f32x4 c0 = gc[n / 4], c1 = gc[n / 4 + 1];
+        float w2[8];
+        gain8(v, make_float4(c0[0], c0[1], c0[2], c0[3]), make_float4(c1[0], c1[1], c1[2], c1[3]), w2);
+        store_h16x8<NP>(y2, (size_t)row * ldx + col, w2, rc);
+      }
+    }
     rc.commit(sf.p, sf.tag);
   }
   template <int BM, int BN, int LD>
@@ -979,6 +1001,9 @@ struct EpiResidualNorm {
       return run48<BM, LD>(s0, m0, n0, tid, aux, sf);
     } else {
     static_assert(BN % 32 == 0, "partial sums of squares are per 32-column group (tiles = D / 32)");
+    static_assert(!Y2 || !DUP, "the duplicating form never feeds a folded query projection");
+    // (Y2 on a tile wider than 32 columns -- the batched path's -- writes no second pair: the launcher folds the query
+    // projection only where the producer runs on narrow tiles, msd_api.hip fold_cross_q)
     const bool pre = BN == 32 && aux_present(aux);
     const int step = pre ? 0 : *step_ptr;
     RangeCheck rc;
@@ -1024,6 +1049,16 @@ struct EpiResidualNorm {
           float w[8];
           gain8(v, g0, g1, w);
           store_h16x8<NP>(y, (size_t)row * ldx + col, w, rc);
+        }
+        if constexpr (Y2 && BN == 32) {
+          if (g2 != nullptr && row < y2_rows) {
+            typedef const __attribute__((address_space(3))) f32x4* lds_g2_t;
+            lds_g2_t gc = (lds_g2_t)(aux + BM * 128 + 2048);
+            const f32x4 c0 = gc[n / 4], c1 = gc[n / 4 + 1];
+            float w2[8];
+            gain8(v, make_float4(c0[0], c0[1], c0[2], c0[3]), make_float4(c1[0], c1[1], c1[2], c1[3]), w2);
+            store_h16x8<NP>(y2, (size_t)row * ldx + col, w2, rc);
+          }
         }
       }
     };
@@ -1103,6 +1138,9 @@ struct EpiInProj {
   const float* g; int g_stride;
   const int* step_ptr;
   int* step_copy = nullptr;   // = step_ptr when the sampler follows in the same step
+  // optional: y2 = x (.) g2 for the first pass's rows -- layer 0's folded cross-attention query projection (EpiResidualNorm Y2)
+  h16_t* y2[2] = {nullptr, nullptr};
+  const float* g2 = nullptr;
   template <int BM, int BN> static constexpr int aux_bytes() { return 0; }
   template <int BM, int BN>
   __device__ void prefetch(char*, int, int, int, int) const {}
@@ -1144,6 +1182,12 @@ struct EpiInProj {
         px[1] = make_float4(v[4], v[5], v[6], v[7]);
         if ((item % (BN / 8)) == 0) ssq[r * tiles + n0 / BN] = sq;
         store_h16x8<NP>(y, r * ldx + col, w, rc);
+      }
+      if (g2 != nullptr) {
+        const float4 c0 = *reinterpret_cast<const float4*>(g2 + col), c1 = *reinterpret_cast<const float4*>(g2 + col + 4);
+        float w2[8];
+        gain8(v, c0, c1, w2);
+        store_h16x8<NP>(y2, (size_t)row * ldx + col, w2, rc);
       }
     }
     rc.commit(sf.p, sf.tag);
@@ -1277,6 +1321,128 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p_in, const Epi& epi, hi
     MSD_LAUNCH_PF(0);
   }
 #undef MSD_LAUNCH_PF
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// The folded cross-attention query projection (round 6; DESIGN.md 5 S6, msd_api.hip decoder_layers).
+//   q = rstd(x1) ((x1 (.) gamma) . Wq),  x1 = x0 + ao . Wo   (network.py:196-198 on the residual of :174-193)
+//     = rstd(x1) ((x0 (.) gamma) . Wq  +  ao . (Wo diag(gamma) Wq))
+// Neither term needs the self-attention output projection: the first rides on the QKV launch's idle CUs (its A operand
+// is written by whichever epilogue produced x0: EpiResidualNorm Y2 / EpiInProj y2), the second runs BESIDE the output
+// projection -- same A operand, one launch -- and adds the first in its epilogue (EpiAddStoreH16); the 1/rms moves
+// onto the logits inside the attention kernel (attention.h AttnParams::q_ssq).  One launch less per decoder layer.
+// Round 3 measured this algebra at 0 ... +1 % (docs/history.md "Hoisting"): its dual launch put both problems on
+// 32 x 32 tiles -- 576 blocks for 512 resident slots, 13.1 us where the two launches took 7.2 + 6.2.  Here each
+// problem keeps its own tile shape and the launch is at most one block per CU (192 + 64 at base).
+// ----------------------------------------------------------------------------
+
+// C (row-major 16-bit planes) = acc + addend[m][n] (fp32).  The addend tile is prefetched into the aux LDS region like
+// the residual tile of EpiResidualNorm, so the epilogue issues no global load.
+template <int NP>
+struct EpiAddStoreH16 {
+  h16_t* out[2];
+  int ldc;
+  const float* addend;
+  int ld_add;
+  template <int BM, int BN> static constexpr int aux_bytes() { return BM * BN * 4; }
+  template <int BM, int BN>
+  __device__ void prefetch(char* aux, int m0, int n0, int wave, int lane) const {
+    constexpr int CPR = BN / 4;   // 16-byte chunks per tile row
+    static_assert((BM * CPR) % 64 == 0, "whole DMA instructions");
+    for (int i = wave; i < BM * CPR / 64; i += 4) {
+      const int id = i * 64 + lane, r = id / CPR, ch = id % CPR;
+      __builtin_amdgcn_global_load_lds((aux_gptr_t)(addend + (size_t)(m0 + r) * ld_add + n0 + ch * 4),
+                                       lds_ptr_of(aux + i * 1024), 16, 0, 0);
+    }
+  }
+  template <int BM, int LD>
+  __device__ void stats(float*, int, int, const char*) const {}
+  template <int BM, int BN, int LD>
+  __device__ void run(float* s0, int m0, int n0, int tid, const char* aux = nullptr, bool stats_done = false,
+                      SatFlag sf = SatFlag()) const {
+    typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4;
+    lds_cf32x4 xs = (lds_cf32x4)(aux);
+    RangeCheck rc;
+    MSD_EPI_ITEMS(BM * BN / 8, item) {
+      const int m = item / (BN / 8), n = (item % (BN / 8)) * 8;
+      float v[8];
+      tile_row8<LD>(s0, m, n, v);
+      const f32x4 a = xs[(m * BN + n) / 4], b = xs[(m * BN + n) / 4 + 1];
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+      store_h16x8<NP>(out, (size_t)(m0 + m) * ldc + n0 + n, v, rc);
+    }
+    rc.commit(sf.p, sf.tag);
+  }
+};
+
+// Two independent GEMMs in ONE launch (no data flows between them), each on its own tile shape and epilogue: blocks
+// [0, n1) run problem 1, the rest problem 2.  n1 is a multiple of 8, so a block's XCD (blockIdx % 8) is the same in the
+// launch-wide and in the problem-local numbering and both problems keep their XCD-aware tile maps.  The launch's weight
+// prefetch target (at most one, p1.pf) is touched by the prefetch waves of all blocks.
+template <int NP, int BM1, int BN1, int NS1, class Epi1, int BM2, int BN2, int NS2, class Epi2, int PF = kPfNone>
+__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_dual_kernel(GemmParams p1, Epi1 e1, GemmParams p2, Epi2 e2, int n1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  warm_kernargs<kernarg_lines<GemmParams, Epi1, GemmParams, Epi2, int>()>();
+  if constexpr (kPfWave && PF != kPfNone) {
+    if (threadIdx.x >= 256) {
+      prefetch_wave<PF>(p1.pf, blockIdx.x, gridDim.x, p1.B[0]);
+      return;
+    }
+  }
+  int bm, bn;
+  if ((int)blockIdx.x < n1) {
+    if (!gemm_block_tile(p1, (int)blockIdx.x, bm, bn)) return;
+    gemm_tile<NP, BM1, BN1, NS1, Epi1, PF>(p1, e1, bm, bn, smem);
+  } else {
+    if (!gemm_block_tile(p2, (int)blockIdx.x - n1, bm, bn)) return;
+    gemm_tile<NP, BM2, BN2, NS2, Epi2, PF>(p2, e2, bm, bn, smem);
+  }
+}
+
+template <int NP, int BM1, int BN1, int NS1, class Epi1, int BM2, int BN2, int NS2, class Epi2>
+constexpr int gemm_h16_dual_smem() {
+  constexpr int a = gemm_h16_dma_smem<NP, BM1, BN1, NS1, Epi1>(), b = gemm_h16_dma_smem<NP, BM2, BN2, NS2, Epi2>();
+  return a > b ? a : b;
+}
+
+// one-time opt-in to > 64 KiB dynamic LDS; call OUTSIDE stream capture
+template <int NP, int BM1, int BN1, int NS1, class Epi1, int BM2, int BN2, int NS2, class Epi2>
+inline hipError_t gemm_h16_dual_prepare() {
+  constexpr int smem = gemm_h16_dual_smem<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2>();
+  if (smem < 64 * 1024) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2, 0>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const hipError_t r = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(gemm_h16_dual_kernel<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2, 1>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return e != hipSuccess ? e : r;
+}
+
+inline int gemm_grid_blocks(const GemmParams& p, int BM, int BN) {
+  const int rx = p.xcd_rows, cx = 8 / rx;
+  return 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
+}
+
+template <int NP, int BM1, int BN1, int NS1, class Epi1, int BM2, int BN2, int NS2, class Epi2>
+inline hipError_t launch_gemm_h16_dual(const GemmParams& p1_in, const Epi1& e1, const GemmParams& p2_in, const Epi2& e2,
+                                       hipStream_t stream) {
+  static_assert(NP == 2, "the folded query projection exists in the two-plane modes only");
+  constexpr int smem = gemm_h16_dual_smem<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2>();
+  static const hipError_t attr = gemm_h16_dual_prepare<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2>();
+  if (attr != hipSuccess) return attr;
+  GemmParams p1 = p1_in, p2 = p2_in;
+  p1.map.fill(p1.M, p1.N, BM1, BN1, p1.xcd_rows);
+  p2.map.fill(p2.M, p2.N, BM2, BN2, p2.xcd_rows);
+  const int n1 = gemm_grid_blocks(p1, BM1, BN1), n2 = gemm_grid_blocks(p2, BM2, BN2);
+  if (prefetch_kind(p1.pf) >= 1)
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2, 1>), dim3(n1 + n2),
+                       dim3(256 + pf_threads(1)), smem, stream, p1, e1, p2, e2, n1);
+  else
+    hipLaunchKernelGGL((gemm_h16_dual_kernel<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2, 0>), dim3(n1 + n2), dim3(256),
+                       smem, stream, p1, e1, p2, e2, n1);
   return hipGetLastError();
 }
 

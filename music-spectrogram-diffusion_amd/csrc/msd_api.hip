@@ -75,6 +75,9 @@ struct DecLayerW {
   Planes wkv_cross[2];  // [2J, D] (k|v)
   Planes wo_cross[2];   // [D, J]
   MlpW mlp;
+  // folded cross-attention query projection (decoder_layers, gemm_h16.h): the modules' Wq^T stacked [n_cross J, D] (one
+  // module: = wq_cross[0]) and W^T of Wo_self . diag(gamma_cross) . Wq_e stacked [n_cross J, J]
+  Planes wq_fold, w2_fold;
 };
 struct EncoderW {
   std::vector<EncLayerW> layers;
@@ -159,6 +162,9 @@ struct msd_model {
   bool dedup_layer0 = true;    // S5 (decoder_layers); msd_config.dedup_layer0 = 2 turns it off for A/B and bitwise tests
   int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   bool merge_in_launch = true; // attention.h attention_inlaunch_merge (msd_config.cross_merge_in_launch = 2 turns it off)
+  bool fold_q = true;          // folded cross-attention query projection (msd_config.cross_q_fold = 2 turns it off)
+  Planes xg;                   // [Bmax T, D] x (.) gamma_cross of the layer about to run, conditional rows (EpiResidualNorm Y2)
+  float* qp = nullptr;         // [Bmax T, n_cross J] (x0 (.) gamma) . Wq, the half of the projection that rides on the QKV launch
   int* att_tickets = nullptr;  // its arrival counters: [Bmax][T / 32][H], zero between launches
   int att_ticket_count = 0;
   int cus = 0;                 // compute units of the device
@@ -391,6 +397,23 @@ void gemm_t(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, 
   c.end(kc);
 }
 
+// launch parameters of one problem of a dual launch (gemm_h16.h gemm_h16_dual_kernel), as gemm_t sets them
+template <int NP>
+GemmParams gp_launch(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, int M, int N, int K, int BM,
+                     const WeightPrefetch* pf = nullptr) {
+  GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+  if (pf) p.pf = *pf;
+  p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+  set_xcd_grid(c.m, p, kc, M, BM);
+  return p;
+}
+template <int NP, int BM1, int BN1, int NS1, int BM2, int BN2, int NS2, class Epi1, class Epi2>
+void gemm_dual_t(Ctx& c, int kc, const GemmParams& p1, const Epi1& e1, const GemmParams& p2, const Epi2& e2) {
+  c.begin(kc);
+  hipError_t e = launch_gemm_h16_dual<NP, BM1, BN1, NS1, Epi1, BM2, BN2, NS2, Epi2>(p1, e1, p2, e2, c.s);
+  if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+  c.end(kc);
+}
 
 constexpr int wide_ns(int np) { return 3; }   // 64 x 64 wide tiles: 3-deep ring (cold weights: deeper is better)
 
@@ -411,6 +434,7 @@ constexpr int big_m_threshold() { return 2048; }   // rows from which the 128-ro
 // epilogues that run on 32 x 48 tiles (gemm_h16.h EpiResidualNorm::run48)
 template <class Epi> struct epi_takes_48 : std::false_type {};
 template <> struct epi_takes_48<EpiResidualNorm<2>> : std::true_type {};
+template <> struct epi_takes_48<EpiResidualNorm<2, false, true>> : std::true_type {};
 
 // The tile a GEMM of kind TK runs on, (BM, BN): ONE rule for the launch below and for whoever prefetches that
 // launch's weights (the prefetcher needs the consumer's column tile and XCD grid).
@@ -529,6 +553,23 @@ hipError_t prepare_gemms() {
   { using EpiDup = EpiResidualNorm<NP, true>; PREP(32, 32, 4, EpiDup) PREP(64, 32, kTallNS, EpiDup) }
   PREP(64, 64, 3, EpiStoreF32)
 #undef PREP
+  if constexpr (NP == 2) {   // the folded cross-attention query projection's dual launches (decoder_layers)
+#define PREP2(BM1, BN1, NS1, E1, BM2, BN2, NS2, E2) \
+    if ((r = gemm_h16_dual_prepare<NP, BM1, BN1, NS1, E1, BM2, BN2, NS2, E2>()) != hipSuccess) e = r;
+    PREP2(64, 96, 3, EpiQKV<NP>, 64, 96, 3, EpiStoreF32) PREP2(64, 64, 3, EpiQKV<NP>, 64, 64, 3, EpiStoreF32)
+    using EpiRN = EpiResidualNorm<NP>; using EpiDup = EpiResidualNorm<NP, true>; using EpiAdd = EpiAddStoreH16<NP>;
+    PREP2(64, 32, kTallNS, EpiRN, 32, 96, 4, EpiAdd) PREP2(32, 32, 4, EpiRN, 32, 96, 4, EpiAdd)
+    PREP2(64, 32, kTallNS, EpiRN, 32, 32, 4, EpiAdd) PREP2(32, 32, 4, EpiRN, 32, 32, 4, EpiAdd)
+    PREP2(64, 32, kTallNS, EpiDup, 32, 96, 4, EpiAdd) PREP2(32, 32, 4, EpiDup, 32, 96, 4, EpiAdd)
+    PREP2(64, 32, kTallNS, EpiDup, 32, 32, 4, EpiAdd) PREP2(32, 32, 4, EpiDup, 32, 32, 4, EpiAdd)
+    {
+      using EpiY2 = EpiResidualNorm<NP, false, true>;
+      if ((r = gemm_h16_dma_prepare<NP, 32, kWide48, 4, EpiY2>()) != hipSuccess) e = r;
+      if ((r = gemm_h16_dma_prepare<NP, 32, 32, 4, EpiY2>()) != hipSuccess) e = r;
+      if ((r = gemm_h16_dma_prepare<NP, 64, 32, kTallNS, EpiY2>()) != hipSuccess) e = r;
+    }
+#undef PREP2
+  }
   return e;
 }
 
@@ -559,7 +600,8 @@ template <int NP>
 void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2], int ldk,
                size_t k_seg_stride, int k_rows, const Planes& vt, int vt_ld, size_t vt_seg_stride,
                const Planes& o, int ldo, const int* n_keys, int q_rows_per_seg, int heads,
-               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1) {
+               int segs, int ksplit = 1, int vt_cols = 0, const WeightPrefetch* pf = nullptr, int qp = -1,
+               const float* q_ssq = nullptr) {
   AttnParams p;
   for (int i = 0; i < 2; ++i) {
     const int j = i < NP ? i : 0;
@@ -573,6 +615,8 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   if (pf) p.pf = *pf;
   p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
   p.qp = qp >= 0 ? qp : (kc == KC_ATTN_SELF ? c.m->att_qp_self : (kc == KC_ATTN_CROSS ? c.m->att_qp_cross : 0));
+  // un-normalised queries (the folded cross-attention query projection): 1/rms from the residual stream's partial sums
+  p.q_ssq = q_ssq; p.q_tiles = c.m->D / kNarrowTile; p.q_inv_d = 1.0f / (float)c.m->D;
   // K / V^T touch-ahead: the decoder's cross-attention (its cache is HBM-cold at every step) at ONE song per handle,
   // where the launch is latency-bound.  Same-process A/B, ms per segment, touches off -> 2 stages ahead
   // (profiles/r05b_touch_ab*.log, r05c_touch_b{2,4}.log): one song 943.1 -> 930.1 (-1.4 %; 4 / 8 ahead: 932.8 / 931.0);
@@ -613,11 +657,13 @@ int pack(msd_model* m, hipStream_t s, const float* w, int K, int N, Planes& dst,
   return MSD_OK;
 }
 
-int pack_attention(msd_model* m, hipStream_t s, const std::string& p, AttnW& a) {
+// `extra_qkv_rows` / `extra_wo_rows`: rows left free BEHIND the packed q|k|v and out matrices in the same allocation (the
+// decoder's folded cross-attention query projection puts its two matrices there: one weight-prefetch target covers both)
+int pack_attention(msd_model* m, hipStream_t s, const std::string& p, AttnW& a, int extra_qkv_rows = 0, int extra_wo_rows = 0) {
   const int D = m->D, J = m->J;
   int rc;
-  if ((rc = palloc(m, &a.wqkv, (size_t)3 * J * D))) return rc;
-  if ((rc = palloc(m, &a.wo, (size_t)D * J))) return rc;
+  if ((rc = palloc(m, &a.wqkv, (size_t)(3 * J + extra_qkv_rows) * D))) return rc;
+  if ((rc = palloc(m, &a.wo, (size_t)(D + extra_wo_rows) * J))) return rc;
   if ((rc = pack(m, s, W(m, p + "/query/kernel"), D, J, a.wqkv, 0, 0))) return rc;
   if ((rc = pack(m, s, W(m, p + "/key/kernel"), D, J, a.wqkv, J, 0))) return rc;
   if ((rc = pack(m, s, W(m, p + "/value/kernel"), D, J, a.wqkv, 2 * J, 0))) return rc;
@@ -995,6 +1041,37 @@ inline int cross_split(const msd_model* m, int batch, int e) {
   return ks;
 }
 
+// S6 (round 6): does decoder layer `l`'s cross-attention query projection run FOLDED into the QKV and attention-out launches
+// (gemm_h16.h "The folded cross-attention query projection")?  One rule for the layer itself, for the producer of its
+// x (.) gamma_cross planes (the previous layer's MLP output projection / the input projection) and for the prefetch plan.
+// `dup`: the layer's self-attention block runs on one pass's rows (S5, layer 0 of a CFG step).  Two-plane modes, narrow
+// tiles (below the batched path's threshold) and a conditional pass only.
+template <int NP>
+bool fold_cross_q(const msd_model* m, int batch, int P, bool cond0, bool dup) {
+  if constexpr (NP != 2) {
+    return false;
+  } else {
+    const int D = m->D, J = m->J, BT = batch * m->T, M = P * BT, Ms = dup ? BT : M, nq = m->n_cross * J;
+    // (up to two songs per call: at three -- M = 1536, several rounds of blocks per launch -- the fold measured +2.4 %,
+    // profiles/r06g_fold_ab_b3.log; the batched path's 128-row tiles from four songs have no narrow epilogue anyway)
+    if (!m->fold_q || !cond0 || M > 1024 || M >= big_m_threshold() || BT % 64 || D / kNarrowTile > kAuxMaxTiles || D % 128) return false;
+    const TileShape tq = pick_tile<NP, TK_QKV>(Ms, 3 * J, 2 * J);
+    if (tq.bm != 64 || nq % tq.bn) return false;
+    const TileShape to = pick_tile<NP, TK_TALL>(Ms, D, 0, true, J);
+    return to.bn == kNarrowTile;
+  }
+}
+
+template <int NP>
+EpiResidualNorm<NP, false, true> with_y2(const EpiResidualNorm<NP>& e, const Planes& y2, const float* g2, int rows) {
+  EpiResidualNorm<NP, false, true> o;
+  o.x = e.x; o.ldx = e.ldx; o.y[0] = e.y[0]; o.y[1] = e.y[1]; o.ssq = e.ssq; o.tiles = e.tiles;
+  o.g_lo = e.g_lo; o.g_lo_stride = e.g_lo_stride; o.g_hi = e.g_hi; o.g_hi_stride = e.g_hi_stride;
+  o.split_row = e.split_row; o.step_ptr = e.step_ptr; o.dup_rows = e.dup_rows;
+  o.y2[0] = y2.p[0]; o.y2[1] = y2.p[NP - 1]; o.g2 = g2; o.y2_rows = rows;
+  return o;
+}
+
 template <int NP>
 void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
   // P passes of `batch` songs: rows [0, BT) are the conditional pass when `cond0`, rows [BT, 2 BT) the unconditional one.
@@ -1037,22 +1114,62 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
     const bool last_layer = (l + 1 == m->Ld);
     const bool dup = dedup0 && l == 0;          // this layer's self-attention block runs on one pass's rows
     const int Ms = dup ? BT : M, Ps = dup ? 1 : P;
+    // S6: this layer's cross-attention query projection is folded into the QKV and attention-out launches
+    const bool fold = fold_cross_q<NP>(m, batch, P, cond0, dup);
+    const int nq = m->n_cross * J;              // the modules' queries, stacked
     {
       const EpiQKV<NP> eq = qkv_epi(l);
-      WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, D, J);
-      gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, Ms, 3 * J, D, eq, eq.v_start, &pf);
+      WeightPrefetch pf = prefetch_of<NP>(m, w.self.wo, fold ? D + nq : D, J);   // (folded: + W2, right behind Wo)
+      bool launched = false;
+      if constexpr (NP == 2) {
+        if (fold) {   // + (x0 (.) gamma_cross) . Wq on the launch's idle CUs, left in float32 for the attention-out launch
+          const TileShape tq = pick_tile<NP, TK_QKV>(Ms, 3 * J, eq.v_start);
+          const GemmParams p1 = gp_launch<NP>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, Ms, 3 * J, D, 64, &pf);
+          const GemmParams p2 = gp_launch<NP>(c, KC_GEMM_QKV, m->xg, D, w.wq_fold, D, BT, nq, D, 64);
+          EpiStoreF32 ef;
+          ef.out = m->qp; ef.ldc = nq;
+          if (tq.bn == 96) gemm_dual_t<NP, 64, 96, 3, 64, 96, 3>(c, KC_GEMM_QKV, p1, eq, p2, ef);
+          else gemm_dual_t<NP, 64, 64, wide_ns(NP), 64, 64, wide_ns(NP)>(c, KC_GEMM_QKV, p1, eq, p2, ef);
+          launched = true;
+        }
+      }
+      if (!launched) gemm<NP, TK_QKV>(c, KC_GEMM_QKV, y, D, w.self.wqkv, D, Ms, 3 * J, D, eq, eq.v_start, &pf);
     }
     const h16_t* kp[2] = {qk.p[0] + J, qk.p[NP - 1] + J};
     // (a self-attention launch on 128-row blocks -- more than one round of 64-row blocks, i.e. from 6 songs per handle --
     // has no prefetch wave: its weight target rides on the out-projection below instead)
     const bool self_qb4 = attention_query_blocks(m->H * (T / 64) * Ps * batch, T, NP) == 4;
-    const WeightPrefetch pf_self = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : prefetch_of<NP>(m, w.wq_cross[0], J, D);
+    const WeightPrefetch pf_self = !cond0 ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D)
+                                          : (fold ? prefetch_of<NP>(m, w.wo_cross[0], D, J) : prefetch_of<NP>(m, w.wq_cross[0], J, D));
     {
       const WeightPrefetch none;
       attention<NP>(c, KC_ATTN_SELF, qk, 2 * J, kp, 2 * J, (size_t)T * 2 * J, T, vts, T,
                     (size_t)J * T, ao, J, nkeys_self, T, m->H, Ps * batch, 1, 0, self_qb4 ? &none : &pf_self);
     }
     const WeightPrefetch* pf_out = self_qb4 ? &pf_self : nullptr;
+    // S6: the output projection and ao . (Wo diag(gamma_cross) Wq_e) in ONE launch -- same A operand; the second problem
+    // adds the half the QKV launch left in `qp` and stores the UN-NORMALISED queries of all modules, [BT, n_cross J]
+    auto attn_out_folded = [&](const auto& epi1, int M1) {
+      if constexpr (NP == 2) {
+        TileShape t1 = pick_tile<NP, TK_TALL>(M1, D, 0, true, J);
+        const bool wide2 = nq % 96 == 0;
+        // the launch should stay within ONE round of the chip: 32 x 32 tiles that fill it by themselves (the small model:
+        // 256 blocks) leave no CU for the second problem -- 64 x 32 then (half the blocks)
+        if (t1.bm == kNarrowTile && M1 % 64 == 0 &&
+            (M1 / 32) * (D / 32) + (BT / 32) * (nq / (wide2 ? 96 : 32)) > 256) t1 = {64, kNarrowTile};
+        const GemmParams p1 = gp_launch<NP>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M1, D, J, t1.bm, pf_out);
+        const GemmParams p2 = gp_launch<NP>(c, KC_GEMM_ATTN_OUT, ao, J, w.w2_fold, J, BT, nq, J, kNarrowTile);
+        EpiAddStoreH16<NP> ea;
+        ea.out[0] = m->cq.p[0]; ea.out[1] = m->cq.p[NP - 1]; ea.ldc = nq; ea.addend = m->qp; ea.ld_add = nq;
+        if (t1.bm == 64) {
+          if (wide2) gemm_dual_t<NP, 64, kNarrowTile, kTallNS, 32, 96, 4>(c, KC_GEMM_ATTN_OUT, p1, epi1, p2, ea);
+          else gemm_dual_t<NP, 64, kNarrowTile, kTallNS, 32, 32, 4>(c, KC_GEMM_ATTN_OUT, p1, epi1, p2, ea);
+        } else {
+          if (wide2) gemm_dual_t<NP, kNarrowTile, kNarrowTile, 4, 32, 96, 4>(c, KC_GEMM_ATTN_OUT, p1, epi1, p2, ea);
+          else gemm_dual_t<NP, kNarrowTile, kNarrowTile, 4, 32, 32, 4>(c, KC_GEMM_ATTN_OUT, p1, epi1, p2, ea);
+        }
+      }
+    };
     // out-projection + residual; produces y for the cross-attention norm (conditional rows:
     // plain gamma) and for the MLP norm (unconditional rows, which skip cross-attention: S4)
     EpiResidualNorm<NP> er;
@@ -1066,7 +1183,12 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
       ed.x = x; ed.ldx = D; ed.y[0] = y.p[0]; ed.y[1] = y.p[NP - 1]; ed.ssq = ssq; ed.tiles = tiles; ed.step_ptr = m->d_step;
       ed.g_lo = er.g_lo; ed.g_lo_stride = er.g_lo_stride; ed.g_hi = er.g_hi; ed.g_hi_stride = er.g_hi_stride;
       ed.split_row = 0; ed.dup_rows = BT;
-      gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, BT, D, J, ed, 0, pf_out);
+      if (fold) attn_out_folded(ed, BT);
+      else gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, BT, D, J, ed, 0, pf_out);
+    } else if (fold) {
+      EpiResidualNorm<NP> ef = er;
+      ef.g_lo = nullptr; ef.g_lo_stride = 0;   // the conditional rows' y = x1 (.) gamma_cross has no reader any more
+      attn_out_folded(ef, M);
     } else
     gemm<NP, TK_TALL>(c, KC_GEMM_ATTN_OUT, ao, J, w.self.wo, J, M, D, J, er, 0, pf_out);
     // (ii) cross-attention block, conditional rows only (S4) (network.py:196-235)
@@ -1074,7 +1196,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
       // every module projects its queries from the SAME normed input (network.py:196-198), so all query
       // projections run before the first output projection rewrites y
       const size_t loff = (size_t)l * m->Bmax * m->S_pad * J;
-      for (int e = 0; e < m->n_cross; ++e) {
+      for (int e = 0; e < m->n_cross && !fold; ++e) {
         const Planes& cq = e == 0 ? m->cq : m->cq2;
         EpiStoreH16<NP> es;
         es.out[0] = cq.p[0]; es.out[1] = cq.p[NP - 1]; es.ldc = J;
@@ -1096,9 +1218,11 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
         const bool warm_mlp_in = e + 1 == m->n_cross && !qb4;
         if (e + 1 == m->n_cross && qb4) mlp_in_on_cross_out = true;
         const WeightPrefetch pf = warm_mlp_in ? prefetch_of<NP>(m, w.mlp.wi, 2 * F, D) : WeightPrefetch();
-        attention<NP>(c, KC_ATTN_CROSS, e == 0 ? m->cq : m->cq2, J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
+        Planes qe = e == 0 ? m->cq : m->cq2;   // folded: module e's columns of the stacked, un-normalised queries
+        if (fold) { qe.p[0] = m->cq.p[0] + (size_t)e * J; qe.p[1] = NP == 2 ? m->cq.p[1] + (size_t)e * J : nullptr; }
+        attention<NP>(c, KC_ATTN_CROSS, qe, fold ? nq : J, kc, J, (size_t)m->S_pad * J, region, vt, m->S_pad,
                       (size_t)J * m->S_pad, e == 0 ? ao : m->ao2, J, m->d_nkeys_cross + (size_t)e * m->Bmax, T, m->H,
-                      batch, ks, region, &pf);
+                      batch, ks, region, &pf, -1, fold ? ssq : nullptr);
       }
       // y = x + sum_e zero_if_masked(MHA_e(...)) (network.py:199-216 / 217-235): residual adds one after the
       // other; the last one also writes the folded-norm inputs of the MLP block
@@ -1124,7 +1248,13 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
     {
       const WeightPrefetch pf_out = prefetch_of<NP>(m, w.mlp.wo, D, F);
       gemm<NP, TK_MLP_IN>(c, KC_GEMM_MLP_IN, y, D, w.mlp.wi, D, M, 2 * F, D, eg, 0, &pf_out);
-      WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J, D);
+      // S6: the next layer's folded query projection reads x (.) gamma_cross of the conditional rows from this epilogue
+      // (and its stacked Wq sits right behind Wq|Wk|Wv: one prefetch target)
+      const bool fold_next = !last_layer && fold_cross_q<NP>(m, batch, P, cond0, false);
+      WeightPrefetch pf_qkv = last_layer ? WeightPrefetch() : prefetch_of<NP>(m, m->dec[l + 1].self.wqkv, 3 * J + (fold_next ? nq : 0), D);
+      if (fold_next)
+        gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, with_y2<NP>(eo, m->xg, m->dec[l + 1].ln_cross, BT), 0, &pf_qkv);
+      else
       gemm<NP, TK_TALL>(c, KC_GEMM_MLP_OUT, gb, F, w.mlp.wo, F, M, D, F, eo, 0, &pf_qkv);
     }
   }
@@ -1148,7 +1278,7 @@ void decoder_layers(Ctx& c, int batch, int P, bool cond0, bool dedup0 = false) {
 }
 
 template <int NP>
-void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {   // P: passes whose rows are written (dedup0: 1)
+void in_proj(Ctx& c, int batch, int P, bool publish_step = false, bool fold0 = false) {   // P: passes whose rows are written (dedup0: 1); fold0: layer 0 folds its cross-attention query projection (S6)
   msd_model* m = c.m;
   const int BT = batch * m->T;
   EpiInProj<NP> ei;
@@ -1156,7 +1286,8 @@ void in_proj(Ctx& c, int batch, int P, bool publish_step = false) {   // P: pass
   ei.y[0] = m->y.p[0]; ei.y[1] = m->y.p[NP - 1]; ei.ssq = m->ssq; ei.tiles = m->D / kNarrowTile;
   ei.g = m->d_g; ei.g_stride = 2 * m->Ld * m->D; ei.step_ptr = m->d_step;   // slot 0 = layer 0 self norm
   ei.step_copy = publish_step ? m->d_step : nullptr;
-  WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J, m->D);
+  if (fold0) { ei.y2[0] = m->xg.p[0]; ei.y2[1] = m->xg.p[NP - 1]; ei.g2 = m->dec[0].ln_cross; }
+  WeightPrefetch pf = prefetch_of<NP>(m, m->dec[0].self.wqkv, 3 * m->J + (fold0 ? m->n_cross * m->J : 0), m->D);
   gemm<NP, TK_NARROW>(c, KC_IN_PROJ, m->zp, m->ND, m->w_in_p, m->ND, BT, m->D, m->ND, ei, 0, &pf);
 }
 
@@ -1172,7 +1303,7 @@ void enqueue_step(Ctx& c, int batch) {
   const int P = m->passes;
   // S5: a CFG step computes layer 0's self-attention block once for both passes
   const bool dedup0 = P == 2 && m->dedup_layer0;
-  in_proj<NP>(c, batch, dedup0 ? 1 : P, /*publish_step=*/true);
+  in_proj<NP>(c, batch, dedup0 ? 1 : P, /*publish_step=*/true, fold_cross_q<NP>(m, batch, P, true, dedup0));
   decoder_layers<NP>(c, batch, P, true, dedup0);
   SamplerParams sp;
   sp.eps = m->eps; sp.z = m->z; sp.noise_slot = m->d_noise_slot; sp.coef = m->d_coef; sp.rng_key = m->d_rng_key;
@@ -1260,7 +1391,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->keep_raw_weights < 0 || cfg->keep_raw_weights > 1) return bad("keep_raw_weights must be 0 or 1");
   if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
   if (cfg->cross_merge_in_launch < 0 || cfg->cross_merge_in_launch > 2) return bad("cross_merge_in_launch must be 0 (library default), 1 (on) or 2 (off)");
-  if (cfg->cross_q_in_attention < 0 || cfg->cross_q_in_attention > 2) return bad("cross_q_in_attention must be 0 (library default), 1 (on) or 2 (off)");
+  if (cfg->cross_q_fold < 0 || cfg->cross_q_fold > 2) return bad("cross_q_fold must be 0 (library default), 1 (on) or 2 (off)");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1277,6 +1408,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   m->dedup_layer0 = cfg->dedup_layer0 != 2;
   if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
   m->merge_in_launch = cfg->cross_merge_in_launch != 2;
+  m->fold_q = cfg->cross_q_fold != 2 && m->NP == 2;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-
@@ -1325,10 +1457,16 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   TRY(palloc(m, &m->qk, Mmax * 2 * J));
   TRY(palloc(m, &m->vt, Mmax * J));
   TRY(palloc(m, &m->ao, Mmax * J));
-  TRY(palloc(m, &m->cq, (size_t)m->Bmax * T * J));
+  // the modules' queries: one allocation -- [Bmax T, J] per module one after the other, or (folded projection, S6) ONE
+  // [BT, n_cross J] matrix of all modules' un-normalised queries
+  TRY(palloc(m, &m->cq, (size_t)m->n_cross * m->Bmax * T * J));
   if (m->n_cross == 2) {
-    TRY(palloc(m, &m->cq2, (size_t)m->Bmax * T * J));
+    for (int i = 0; i < m->NP; ++i) m->cq2.p[i] = m->cq.p[i] + (size_t)m->Bmax * T * J;
     TRY(palloc(m, &m->ao2, (size_t)m->Bmax * T * J));
+  }
+  if (m->fold_q) {
+    TRY(palloc(m, &m->xg, (size_t)m->Bmax * T * D));
+    TRY(dalloc(m, &m->qp, (size_t)m->Bmax * T * m->n_cross * J));
   }
   TRY(palloc(m, &m->g, Mmax * F));
   TRY(dalloc(m, &m->h32, Mmax * D));
@@ -1440,7 +1578,8 @@ int msd_finalize_weights(msd_model* m, void* stream) {
     w.ln_self = W(m, lp + "/pre_self_attention_layer_norm/scale");
     w.ln_cross = W(m, lp + "/pre_cross_attention_layer_norm/scale");
     w.ln_mlp = W(m, lp + "/pre_mlp_layer_norm/scale");
-    if ((rc = pack_attention(m, s, lp + "/self_attention", w.self))) return rc;
+    const int nq_fold = m->fold_q ? m->n_cross * J : 0;
+    if ((rc = pack_attention(m, s, lp + "/self_attention", w.self, nq_fold, nq_fold))) return rc;
     for (int e = 0; e < m->n_cross; ++e) {
       const std::string cp = lp + "/MultiHeadDotProductAttention_" + std::to_string(e);
       if ((rc = palloc(m, &w.wq_cross[e], (size_t)J * D))) return rc;
@@ -1452,6 +1591,32 @@ int msd_finalize_weights(msd_model* m, void* stream) {
       if ((rc = pack(m, s, W(m, cp + "/out/kernel"), J, D, w.wo_cross[e], 0, 0))) return rc;
     }
     if ((rc = pack_mlp(m, s, lp + "/mlp", w.mlp))) return rc;
+    if (m->fold_q) {
+      // S6: (x1 (.) gamma) . Wq with x1 = x0 + ao . Wo  ==  (x0 (.) gamma) . Wq + ao . (Wo diag(gamma) Wq): the second
+      // matrix per module, accumulated in float64, rounded once to float32 and packed like any other weight; the modules'
+      // matrices are stacked along N (one launch projects the queries of all modules)
+      // Both live behind the self-attention's matrices of the same row length (pack_attention left the rows free):
+      // [Wq|Wk|Wv ; Wq_cross] is ONE prefetch target of the previous layer's MLP output projection, [Wo ; W2] one of the
+      // QKV launch -- no launch carries a prefetch wave it did not carry before the fold.
+      for (int i = 0; i < 2; ++i) {
+        w.wq_fold.p[i] = w.self.wqkv.p[i] ? w.self.wqkv.p[i] + (size_t)3 * J * D : nullptr;
+        w.w2_fold.p[i] = w.self.wo.p[i] ? w.self.wo.p[i] + (size_t)D * J : nullptr;
+      }
+      for (int e = 0; e < m->n_cross; ++e)
+        if ((rc = pack(m, s, W(m, lp + "/MultiHeadDotProductAttention_" + std::to_string(e) + "/query/kernel"), D, J, w.wq_fold, e * J, 0))) return rc;
+      float* w2 = nullptr;
+      HIP_TRY(m, hipMalloc(&w2, (size_t)J * J * sizeof(float)));
+      for (int e = 0; e < m->n_cross && rc == MSD_OK; ++e) {
+        hipLaunchKernelGGL(fold_wq_kernel, dim3((J + 15) / 16, (J + 15) / 16), dim3(16, 16), 0, s,
+                           W(m, lp + "/self_attention/out/kernel"), w.ln_cross,
+                           W(m, lp + "/MultiHeadDotProductAttention_" + std::to_string(e) + "/query/kernel"), w2, J, D, J);
+        rc = pack(m, s, w2, J, J, w.w2_fold, e * J, 0);
+      }
+      const hipError_t es = hipStreamSynchronize(s);
+      (void)hipFree(w2);
+      if (rc) return rc;
+      HIP_TRY(m, es);
+    }
   }
   m->dec_final_ln = W(m, "decoder/decoder_norm/scale");
   m->w_spec_out = W(m, "decoder/spec_out_dense/kernel");
@@ -1665,7 +1830,7 @@ int msd_decoder_pass(msd_model* m, int batch, int step_index, const float* z_dev
   HIP_TRY(m, hipStreamSynchronize(s));
   split_z(m, n, s);
   Ctx c{m, s};
-  if (m->NP == 2) { in_proj<2>(c, batch, 1); decoder_layers<2>(c, batch, 1, include_conditioning != 0); }
+  if (m->NP == 2) { in_proj<2>(c, batch, 1, false, fold_cross_q<2>(m, batch, 1, include_conditioning != 0, false)); decoder_layers<2>(c, batch, 1, include_conditioning != 0); }
   else { in_proj<1>(c, batch, 1); decoder_layers<1>(c, batch, 1, include_conditioning != 0); }
   if (c.err != hipSuccess) return fail(m, MSD_ERR_HIP, "decoder pass failed: %s", hipGetErrorString(c.err));
   HIP_TRY(m, hipMemcpyAsync(eps_out_dev, m->eps, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1702,6 +1867,9 @@ int msd_debug_read(msd_model* m, const char* buffer, float* host_out, int64_t ma
   else if (b == "vt") { pl = &m->vt; count = Mmax * m->J; }
   else if (b == "ao") { pl = &m->ao; count = Mmax * m->J; }
   else if (b == "g") { pl = &m->g; count = Mmax * m->F; }
+  else if (b == "cq") { pl = &m->cq; count = (int64_t)m->n_cross * m->Bmax * m->T * m->J; }
+  else if (b == "xg" && m->fold_q) { pl = &m->xg; count = (int64_t)m->Bmax * m->T * m->D; }
+  else if (b == "qp" && m->fold_q) { f32 = m->qp; count = (int64_t)m->Bmax * m->T * m->n_cross * m->J; }
   else if (b == "enc") { pl = &m->enc; count = (int64_t)m->S_pad * m->D; }
   else if (b == "cross_k") { pl = &m->kc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }
   else if (b == "cross_vt") { pl = &m->vtc; count = (int64_t)m->Ld * m->Bmax * m->S_pad * m->J; }

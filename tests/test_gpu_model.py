@@ -585,6 +585,89 @@ def test_exact_launch_shortcuts_are_bit_identical(preset, steps):
       assert np.array_equal(outs['kv_touch_ahead off'], outs['default'])
 
 
+@pytest.mark.parametrize('preset,style,nb', [('tiny_context', 'concat', 2), ('tiny_context', 'sum', 2), ('tiny', 'concat', 1),
+                                             ('small', 'concat', 1), ('base_with_context', 'concat', 1),
+                                             ('base_with_context', 'concat', 3), ('base_with_context', 'sum', 1)])
+def test_folded_cross_query_projection_is_the_same_function(preset, style, nb):
+  """S6 (round 6; msd_config.cross_q_fold): the cross-attention's query projection has no launch of its own.  With
+  x1 = x0 + ao . Wo (network.py:174-193) the projection's input is rstd(x1) (x1 (.) gamma) (network.py:196-198, layers.py:632-666), so
+    (x1 (.) gamma) . Wq = (x0 (.) gamma) . Wq + ao . (Wo diag(gamma) Wq):
+  the first term rides on the QKV launch, the second runs beside the self-attention output projection, the 1/rms scales
+  the logits inside the attention kernel.  Exact algebra, another rounding order: single decoder passes with the fold on
+  (library default) and off must agree to float32 rounding AND both must sit on the float64 oracle like every other
+  pass (2e-4 max-rel: tests above); a CFG segment of a few steps must stay in the float32 class.  Both cross-attention
+  styles (one and two modules), the duplicating layer 0 (CFG), 1 - 3 songs (M = 512 ... 1536: narrow tiles)."""
+  import dataclasses
+  import torch
+  from oracle import backend, fast
+  steps = 4
+  spec = msd_amd.config.preset(preset, num_steps=steps)
+  if style == 'sum':
+    spec = dataclasses.replace(spec, t5=dataclasses.replace(spec.t5, decoder_cross_attend_style='sum_cross_attends'))
+  params = msd_amd.synthetic.init_params(spec, 5, norm_scale_jitter=0.1)
+  t = spec.task_feature_lengths['targets']
+  batch = helpers.make_batch(spec, batch=nb, ctx_mask='ragged') if spec.has_context else \
+      {'encoder_input_tokens': np.concatenate([msd_amd.synthetic.segment_tokens(spec, 70 + b) for b in range(nb)], 0)}
+  cfg, dc = helpers.oracle_configs(spec)
+  small_enough = preset.startswith('tiny')
+  fm = None
+  if small_enough:
+    fm = fast.FastModel(backend.NumpyBackend('float64'), cfg, dc, params, spec.has_context)
+    if spec.has_context:
+      fm.encode(batch['encoder_input_tokens'], batch['encoder_continuous_inputs'], batch['encoder_continuous_mask'])
+    else:
+      fm.encode(batch['encoder_input_tokens'])
+  z = np.random.default_rng(1).standard_normal((nb, t, 128)).astype(np.float32)
+  zd = torch.as_tensor(z).cuda()
+  init_z, noise = helpers.make_noise(spec, batch=nb)
+  eps, seg = {}, {}
+  for fold in (True, False):
+    model = msd_amd.InferenceModel(params, spec, batch_size=nb, cross_q_fold=fold, **helpers.ALL_PLANES)
+    nm = model._get_native()
+    if spec.has_context:
+      nm.encode(nb, batch['encoder_input_tokens'], torch.as_tensor(batch['encoder_continuous_inputs']).cuda(),
+                batch['encoder_continuous_mask'])
+    else:
+      nm.encode(nb, batch['encoder_input_tokens'])
+    for step, cond in ((steps - 1, True), (1, True), (0, False)):
+      out = torch.zeros_like(zd)
+      nm.decoder_pass(nb, step, zd, cond, out)
+      torch.cuda.synchronize()
+      eps[fold, step] = out.cpu().numpy()
+      if fm is not None:
+        want = fm.decoder_pass(z.astype(np.float64), step, cond)
+        err = np.abs(eps[fold, step] - want).max() / np.abs(want).max()
+        assert err < 2e-4, (preset, style, fold, step, cond, err)
+    got, _ = model.predict(batch, init_z=init_z, noise=noise)   # CFG steps: the duplicating layer 0 + the fold
+    seg[fold] = np.asarray(got)
+    del model, nm
+    torch.cuda.empty_cache()
+  for step in (steps - 1, 1, 0):
+    rel = np.abs(eps[True, step] - eps[False, step]).max() / np.abs(eps[False, step]).max()
+    print('%s/%s, %d song(s), step %d: folded vs unfolded decoder pass, max rel %.2e' % (preset, style, nb, step, rel))
+    assert rel < (2e-5 if step else 1e-30), (preset, style, step, rel)   # (step 0 ran unconditional: no cross-attention, same bits)
+  assert np.isfinite(seg[True]).all()
+  if small_enough:
+    # a few huge steps amplify rounding (helpers.assert_fp32_class): both orders must show the float32 oracle's error
+    # distribution -- the folded one no worse than the unfolded one (tests/diag/fold_stats.py, profiles/r06d_fold_stats.log:
+    # the fractions beyond 1e-3 / 1e-4 agree to 0.003 over 16 cases)
+    ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
+    ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
+    e32 = np.abs(ref32 - ref64).ravel()
+    for tau in (1e-3, 1e-4):
+      f = {k: float((np.abs(seg[k].astype(np.float64) - ref64).ravel() > tau).mean()) for k in (True, False)}
+      f32 = float((e32 > tau).mean())
+      print('%s/%s beyond %.0e: folded %.4f unfolded %.4f float32 oracle %.4f' % (preset, style, tau, f[True], f[False], f32))
+      assert f[True] <= 1.05 * f[False] + 0.003, (preset, style, tau, f)
+      assert f[True] <= 1.30 * f32 + 0.01, (preset, style, tau, f, f32)
+    med = {k: float(np.median(np.abs(seg[k].astype(np.float64) - ref64))) for k in (True, False)}
+    assert med[True] <= 1.5 * float(np.median(e32)) + 1e-6, med
+  else:   # the two orders stay together to that class
+    d = seg[True] - seg[False]
+    print('%s/%s: folded vs unfolded %d-step segment: rms %.2e, max %.2e' % (preset, style, steps, np.sqrt((d ** 2).mean()), np.abs(d).max()))
+    assert np.sqrt((d ** 2).mean()) < 1e-3, (preset, style)
+
+
 @pytest.mark.parametrize('preset,nb', [('tiny_context', 1), ('tiny_context', 3), ('small', 1)])
 def test_sampler_draws_the_step_noise_itself_bit_identical(preset, nb):
   """msd_sample with noise == NULL (round 6): sampler_step_kernel draws step i's noise from sub-sequence 1 + i of the

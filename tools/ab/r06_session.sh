@@ -23,6 +23,45 @@ second)  # in-launch merge of the key-split cross-attention: op-level and model-
   mkdir -p $OUT/${TAG}_selfprof
   timeout 600 python bench.py --no-cpu-baseline --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 300 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
   ;;
+third)  # folded cross-attention query projection (S6): parity tests, in-process A/B, bench with its own kernel trace
+  timeout 1500 python -m pytest tests/test_gpu_model.py -m gpu -q -x -s -k "folded_cross_query or exact_launch or sum_cross or encode_and_single or does_not_depend_on_the_batch or batched_songs" > $OUT/${TAG}_fold_tests.log 2>&1; tail -4 $OUT/${TAG}_fold_tests.log; grep "folded vs unfolded" $OUT/${TAG}_fold_tests.log | head -40
+  timeout 500 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_fold_ab.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --tokens 300 --tokens 1300 --json $OUT/${TAG}_fold_ab2.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab2.log
+  timeout 300 python tools/ab/knob_ab.py --preset small --rounds 4 --json $OUT/${TAG}_fold_ab_small.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_small.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --batch 2 --steps 500 --json $OUT/${TAG}_fold_ab_b2.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_b2.log
+  mkdir -p $OUT/${TAG}_selfprof
+  timeout 600 python bench.py --no-cpu-baseline --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 300 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
+  ;;
+fourth)  # the fold after: stage 0 peeled in the QS attention kernel, fold matrices behind Wqkv / Wo (no extra prefetch waves)
+  timeout 600 python tests/diag/fold_stats.py --seeds 4 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_stats.log | tail -8
+  timeout 500 python tools/ab/knob_ab.py --rounds 5 --json $OUT/${TAG}_fold_ab.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --tokens 300 --tokens 1300 --json $OUT/${TAG}_fold_ab2.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab2.log
+  timeout 300 python tools/ab/knob_ab.py --preset small --rounds 4 --json $OUT/${TAG}_fold_ab_small.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_small.log
+  mkdir -p $OUT/${TAG}_selfprof
+  timeout 600 python bench.py --no-cpu-baseline --batched-songs 0 --small-segments 0 --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 300 $OUT/${TAG}_bench_default.json; tail -3 $OUT/${TAG}_bench_default.err
+  ;;
+fifth)  # same-box kernel traces of both orders (bench self-profile with --knob)
+  mkdir -p $OUT/${TAG}_selfprof_fold $OUT/${TAG}_selfprof_plain
+  for v in plain fold; do
+    K="cross_q_fold=$([ $v = fold ] && echo True || echo False)"
+    timeout 400 python bench.py --steps 3 --no-cpu-baseline --batched-songs 0 --small-segments 0 --knob $K --self-profile-keep $OUT/${TAG}_selfprof_$v > $OUT/${TAG}_bench_$v.json 2> $OUT/${TAG}_bench_$v.err; tail -c 200 $OUT/${TAG}_bench_$v.json; tail -2 $OUT/${TAG}_bench_$v.err
+  done
+  ;;
+sixth)  # two tools on one box: alternating processes (bench) and one process with both models (knob_ab, both orders)
+  for i in 1 2; do for v in plain fold; do
+    K="cross_q_fold=$([ $v = fold ] && echo True || echo False)"
+    timeout 300 python bench.py --steps 3 --no-cpu-baseline --batched-songs 0 --small-segments 0 --no-self-profile --knob $K 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('$v', d['value'], d['ms_per_step'])" | tee -a $OUT/${TAG}_process_ab.log
+  done; done
+  timeout 500 python tools/ab/knob_ab.py --rounds 4 --json $OUT/${TAG}_fold_ab.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab.log
+  timeout 500 python tools/ab/knob_ab.py --rounds 4 --json $OUT/${TAG}_fold_ab_rev.json 'cross_q_fold=True' 'cross_q_fold=False' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_rev.log
+  timeout 500 python tools/ab/knob_ab.py --rounds 4 --tokens 900 --json $OUT/${TAG}_fold_ab_900.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_900.log
+  ;;
+seventh)  # fold: full GPU suite + small / 2 / 3 songs A/B
+  timeout 2400 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
+  timeout 300 python tools/ab/knob_ab.py --preset small --rounds 4 --json $OUT/${TAG}_fold_ab_small.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_small.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --batch 2 --steps 500 --tokens 900 --json $OUT/${TAG}_fold_ab_b2.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_b2.log
+  timeout 400 python tools/ab/knob_ab.py --rounds 3 --batch 3 --steps 300 --tokens 900 --json $OUT/${TAG}_fold_ab_b3.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_b3.log
+  ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
