@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MSD_AMD_ABI_VERSION 6   /* 6: cross_merge_in_launch, cross_q_fold appended to msd_config.
+#define MSD_AMD_ABI_VERSION 6   /* 6: cross_merge_in_launch, cross_q_fold, mlp_in_persistent appended to msd_config.
                                    5: dedup_layer0, cross_key_split, keep_raw_weights, kv_touch_ahead appended to msd_config.
                                    4: every caller-selectable knob is a msd_config field (attn_q_planes / attn_p_planes
                                       replace ABI 3's attn_query_planes; graph_steps; weight_prefetch): the library reads
@@ -191,6 +191,12 @@ typedef struct msd_config {
                                      the attention kernel.  Same float32-class result, NOT bit-identical to the unfolded
                                      order (3e-7 relative on a decoder pass).  Two-plane precisions, up to 3 songs per
                                      call.  0 = the library's choice (on), 1 = on, 2 = off */
+  int32_t mlp_in_persistent;      /* batched songs (>= 4 per call: 128 x 128 tiles, several per CU): the decoder's gated-MLP
+                                     input projection runs as ONE resident block per CU that walks its tiles, with the
+                                     epilogue on the accumulator registers and the next tile's operands landing under
+                                     it.  Same float32-class result, not bit-identical to the per-tile launch (another
+                                     contraction of the epilogue's multiply-adds).  0 = the library's choice (on), 1 = on,
+                                     2 = off */
 } msd_config;
 
 const char* msd_version(void);

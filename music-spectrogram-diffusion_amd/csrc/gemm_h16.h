@@ -248,8 +248,22 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
 // ----------------------------------------------------------------------------
 // One output tile (bm, bn) by the 256 threads of the calling block; `smem` = the block's dynamic LDS
 // (gemm_h16_dma_smem bytes).
-template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem) {
+// accumulators of one wave's share of a BM x BN tile in the 2 x 2 wave layout (what gemm_tile hands to a register epilogue)
+template <int BM, int BN>
+struct GemmAcc {
+  static constexpr int FM = BM / 32, FN = BN / 32;
+  f32x4 a[FM][FN];
+};
+
+// PROLOGUE = false / REG_EPI = true (the persistent gated-MLP-in kernel below): the caller has already issued the tile's
+// first NS K-tiles and the epilogue operands (gemm_tile_issue + Epi::prefetch), and takes the accumulators back in
+// registers right behind the loop -- the ring is free from that point on (no slab), e.g. for the NEXT tile's K-tiles.
+template <int NP, int BM, int BN, int NS, class Epi, int PF = kPfNone, bool PROLOGUE = true, bool REG_EPI = false>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, int bm, int bn, char* smem,
+                                          GemmAcc<BM, BN>* acc_out = nullptr, int ts_blk = -1, bool fresh = false) {
+#if MSD_TIMESTAMPS
+  const int msd_ts_blk = ts_blk >= 0 ? ts_blk : (int)blockIdx.x;   // which record the phase stamps of this tile go to
+#endif
   // Wave layout.  2 x 2 waves of (BM/2) x (BN/2) by default.  W13 (BN == 48: the 32 x 48 tile, 256 tiles of a
   // 512 x 768 output = one per CU): three compute waves side by side, each the full 32 rows x 16 columns; wave 3
   // SHADOWS wave 2 (same fragment reads, same MFMAs, no slab store): it is there for its quarter of the DMA issue, and
@@ -327,18 +341,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / kGemmBK;
-  MSD_TS_BEGIN((ts_class<BM, BN>()), blockIdx.x)
+  MSD_TS_BEGIN((ts_class<BM, BN>()), msd_ts_blk)
   // ---- prologue: all NS ring slots are free, so NS K-tiles go in flight at once -------
+  if constexpr (PROLOGUE) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-    if (s < nk) MSD_D_ISSUE(s, s)
+    for (int s = 0; s < NS; ++s)
+      if (s < nk) MSD_D_ISSUE(s, s)
+  }
   // Epilogue operands (row statistics, step-indexed bias / gain rows, the residual tile) are
   // HBM-cold and used to be read by dependent global loads AFTER the K loop (+2..4 us per
   // launch).  They are DMAed into an aux LDS region behind the ring now, queued behind the
   // first tiles: vmcnt retires in order, so the loop's counted waits stay valid (they can only
   // over-wait by these few instructions) and the final vmcnt(0) covers them.
   char* const aux = smem + NS * STAGE_BYTES;
-  epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
+  if constexpr (PROLOGUE) epi.template prefetch<BM, BN>(aux, m0, n0, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   MSD_TS_STAMP(BM, BN, 1)
 
@@ -429,9 +445,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
     buf = nb;                                                                                \
   }
 
-  if (nk >= NS) {
+  // (`fresh`, !PROLOGUE only: the caller issued exactly what the prologue issues and nothing since -- a block's first tile)
+  if ((PROLOGUE || fresh) && nk >= NS) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PW) : "memory");  // tile 0 landed; NS-1 tiles in flight
-  } else {
+  } else {   // (!PROLOGUE: the previous tile's epilogue STORES sit between the caller's DMAs and here -- vmcnt counts them too)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -467,6 +484,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
 #undef MSD_A_SRC
   __syncthreads();  // all fragment reads done before the slab overwrites the ring
   MSD_TS_STAMP(BM, BN, 3)
+  if constexpr (REG_EPI) {
+    static_assert(!W13, "register epilogues: 2 x 2 wave layout");
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc_out->a[i][j] = acc[i][j];
+    return;
+  } else {
   float* slab = reinterpret_cast<float*>(smem);
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   auto store_slab = [&]() {
@@ -489,8 +514,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const Epi& epi, i
   MSD_TS_STAMP(BM, BN, 4)
   epi.template run<BM, BN, LDS_LD>(slab, m0, n0, tid, aux, /*stats_done=*/true, SatFlag{p.sat, p.sat_tag});
   MSD_TS_STAMP(BM, BN, 5)
-  MSD_TS_END((ts_class<BM, BN>()), blockIdx.x, gridDim.x)
+  MSD_TS_END((ts_class<BM, BN>()), msd_ts_blk, gridDim.x)
   prefetch_done(pf_keep);
+  }
 }
 
 // XCD-aware tile map (block b runs on XCD b % 8): XCD x owns the column tiles bn = x, x+8, ...
@@ -1321,6 +1347,223 @@ inline hipError_t launch_gemm_h16_dma(const GemmParams& p_in, const Epi& epi, hi
     MSD_LAUNCH_PF(0);
   }
 #undef MSD_LAUNCH_PF
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Batched songs: the gated-MLP input projection as a PERSISTENT tile loop with a register epilogue (round 6; VERDICT r05
+// next #3).  At >= 4 songs per handle a CU runs 4 .. 8 of the 128 x 128 tiles back to back and a tile lives 17.4 us of
+// which 11.8 are its main loop (profiles/r05z_phase_times_b8.txt): 2.0 issuing the two ring stages (the ingest rate),
+// 0.5 waiting for the first, 1.1 storing the accumulators to the LDS slab, 1.9 in the epilogue.  The slab lives in the
+// ring, so nothing of the next tile could start before the epilogue had read it.  Here
+//   * the epilogue works on the accumulator REGISTERS: in the packed wi_0 | wi_1 column order a lane's accumulators
+//     (i, 2q) and (i, 2q + 1) are the gelu input and the gate of the SAME four output columns -- no slab, no transpose;
+//   * the block stays alive over its tiles (virtual block v = blockIdx + k * gridDim: the XCD-aware tile map of the
+//     plain launch, same XCD for every k) and issues tile k + 1's two ring stages right behind tile k's main loop, in
+//     front of tile k's epilogue: the stages land while the epilogue computes and stores.
+// vmcnt counts the epilogue's stores, which are younger than those DMAs: the next tile starts with vmcnt(0) (its stages
+// have had the whole epilogue to land) and keeps the loop's counted waits from there.
+// ----------------------------------------------------------------------------
+
+// The first NS K-tiles of tile (bm, bn) into the ring, 2 x 2 wave layout: the prologue of gemm_tile as a function, its
+// NS * NP * (BM + BN) / 32 LDS-DMA instructions per wave addressable one by one (Q0 <= q < Q1) so that a caller can
+// spread them between other work: a wave cannot issue past a DMA the address unit has not taken yet, and a whole
+// prologue is ~2 us of that (the "entry -> prologue DMAs issued" of the phase stamps).
+template <int NP, int BM, int BN, int NS>
+struct GemmTileIssue {
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = NP * (A_BYTES + B_BYTES);
+  static constexpr int A_LD = BM / 32, B_LD = BN / 32, PER_PLANE = A_LD + B_LD, PER_STAGE = NP * PER_PLANE, COUNT = NS * PER_STAGE;
+  const h16_t* ga[NP];
+  const h16_t* gb[NP];
+  size_t a_step, b_step;
+  char* smem;
+  int wave;
+  // `as_wave` >= 0: issue the share of compute wave `as_wave` (a loader wave standing in for the four of them)
+  __device__ __forceinline__ GemmTileIssue(const GemmParams& p, int bm, int bn, char* smem_, int as_wave = -1) : smem(smem_) {
+    const int lane = threadIdx.x & 63;
+    wave = as_wave >= 0 ? as_wave : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int r8 = lane >> 3, csrc = (lane & 7) ^ r8;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      ga[pl] = p.A[pl] + (size_t)(bm * BM + wave * (BM / 4) + r8) * p.lda + csrc * 8;
+      gb[pl] = p.B[pl] + (size_t)(bn * BN + wave * (BN / 4) + r8) * p.ldb + csrc * 8;
+    }
+    a_step = (size_t)8 * p.lda; b_step = (size_t)8 * p.ldb;
+  }
+  template <int Q0, int Q1>
+  __device__ __forceinline__ void issue() const {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+      if (q >= COUNT) break;
+      const int st = q / PER_STAGE, pl = (q % PER_STAGE) / PER_PLANE, r = q % PER_PLANE;
+      char* base = smem + st * STAGE_BYTES;
+      if (r < A_LD)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga[pl] + r * a_step + st * kGemmBK),
+                                         (lptr_t)(base + pl * A_BYTES + (wave * (BM / 4) + 8 * r) * 128), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[pl] + (r - A_LD) * b_step + st * kGemmBK),
+                                         (lptr_t)(base + NP * A_BYTES + pl * B_BYTES + (wave * (BN / 4) + 8 * (r - A_LD)) * 128), 16, 0, 0);
+    }
+  }
+};
+
+template <int NP>
+__device__ __forceinline__ void store_h16x4(h16_t* const* planes, size_t off, const float v[4], RangeCheck& rc) {
+  uint32_t wh[2], wl[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    rc.see(v[2 * e], v[2 * e + 1]);
+    if (NP == 2) split2_h16(v[2 * e], v[2 * e + 1], wh[e], wl[e]);
+    else wh[e] = cvt2_h16(v[2 * e], v[2 * e + 1]);
+  }
+  *reinterpret_cast<uint2*>(planes[0] + off) = make_uint2(wh[0], wh[1]);
+  if (NP == 2) *reinterpret_cast<uint2*>(planes[1] + off) = make_uint2(wl[0], wl[1]);
+}
+
+template <int NP, int BM, int BN, int NS>
+constexpr int gemm_h16_geglu_persist_smem() { return NS * NP * (BM + BN) * 128 + rowscale_aux_bytes<BM>() + BM * 4; }   // ring, aux rows, rstd
+
+// `vblocks`: blocks of the plain launch's grid (GemmParams::TileMap: 8 x column groups x row groups; some map to no
+// tile).  The launcher folds the norm (rsc.ssq) and has a step-indexed bias row (rsc.bias): the decoder's MLP blocks.
+// The row statistics are per ROW tile: a block whose successive tiles keep their row tile (grid / 8 a multiple of the
+// row tiles per XCD row group: every shipped batch) computes them -- and fetches their partial sums -- once.
+//
+// What was measured on the way (8 songs per handle, same-process A/B against the per-tile launch, stamps of a debug
+// build: profiles/r06i ... r06l_persist_ab_b*.log, r06l_phase_times_b8.txt):
+//   * this form (the next tile's stages issued as ONE block behind the main loop, in front of the epilogue): tile
+//     lifetime 18.97 -> 17.6 us, -0.8 ... -1.9 % end to end.  The issue itself blocks the compute waves for ~2 us (a wave
+//     stalls at a DMA the address unit has not taken, and 128 KiB are 2 us of the CU's ingest rate), so what overlaps
+//     the epilogue's arithmetic is the LANDING, not the issue;
+//   * the same DMAs spread between the epilogue's eight output groups: the epilogue 1.9 -> 3.45 us, no better;
+//   * a fifth, LOADER wave that issues them while the four compute waves run the epilogue (it mirrors their barriers):
+//     one wave issues a DMA per ~65 clocks -- 128 of them are 5 us -- and the next tile waited 2.9 us for it: +1 ... +1.5 %.
+// A tile is 768 KiB through a CU that ingests ~35 B/clk: 11.9 us of its 17.6 at these clocks; the rest is the per-K-tile
+// synchronisation of a two-stage ring (the loop's 12.9 us against 10.3 of MFMA issue), which no epilogue overlap touches.
+// (One song, one 64 x 128 tile per block through this kernel -- the register epilogue without a tile loop: +0.5 % step,
+// its 8-byte stores cover 32 contiguous bytes per row where the slab's cover 128; not used.)
+template <int NP, int BM, int BN, int NS, int PF = kPfNone>
+__global__ void __launch_bounds__(256 + pf_threads(PF)) gemm_h16_geglu_persist_kernel(GemmParams p, EpiGeglu<NP> epi, int vblocks) {
+  static_assert(BM % 32 == 0 && BN % 64 == 0, "2 x 2 waves; whole wi_0 | wi_1 groups per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  warm_kernargs<kernarg_lines<GemmParams, EpiGeglu<NP>, int>()>();
+  if constexpr (kPfWave && PF != kPfNone) {
+    if (threadIdx.x >= 256) {
+      prefetch_wave<PF>(p.pf, blockIdx.x, gridDim.x, p.B[0]);
+      return;
+    }
+  }
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int STAGE_BYTES = NP * (BM + BN) * 128;
+  typedef GemmTileIssue<NP, BM, BN, NS> Issue;
+  char* const aux = smem + NS * STAGE_BYTES;
+  float* const rs = reinterpret_cast<float*>(aux + rowscale_aux_bytes<BM>());
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lm = lane & 15, ln = (lane >> 4) * 4;
+  const int step = (int)gridDim.x;
+  int v = blockIdx.x, bm = 0, bn = 0;
+  bool have = false;
+  for (; v < vblocks; v += step)
+    if (gemm_block_tile(p, v, bm, bn)) { have = true; break; }
+  if (!have) return;
+  // epilogue operands of a tile: the bias row of its columns and -- a new row tile only -- the partial sums of squares of
+  // its rows (EpiGeglu::prefetch = rowscale_prefetch, split so that the statistics move once per row tile)
+  auto operands = [&](int tbm, int tbn, bool with_stats) {
+    if (with_stats) aux_dma_linear(epi.rsc.ssq + (size_t)tbm * BM * epi.rsc.tiles, aux, BM * epi.rsc.tiles * 4, wave, lane);
+    if (wave == 3)
+      aux_dma_row(epi.rsc.bias + (size_t)scan_index(epi.rsc.step_ptr) * epi.rsc.bias_step_stride + tbn * BN,
+                  aux + rowscale_ssq_bytes<BM>(epi.rsc.tiles), BN * 4, lane);
+  };
+  {
+    const Issue first(p, bm, bn, smem);
+    first.template issue<0, Issue::COUNT>();
+  }
+  operands(bm, bn, true);
+  bool stats_stale = true;
+  for (;;) {
+    GemmAcc<BM, BN> acc;
+    const int vcur = v;   // (debug builds: this tile's phase-stamp record)
+    gemm_tile<NP, BM, BN, NS, EpiGeglu<NP>, PF, /*PROLOGUE=*/false, /*REG_EPI=*/true>(p, epi, bm, bn, smem, &acc, vcur, /*fresh=*/stats_stale && vcur == (int)blockIdx.x);
+    const int m0 = bm * BM, n0 = bn * BN;
+    int nbm = 0, nbn = 0;
+    bool more = false;
+    for (v += step; v < vblocks; v += step)
+      if (gemm_block_tile(p, v, nbm, nbn)) { more = true; break; }
+    if (more) {   // the ring is free: the accumulators stay in registers
+      const Issue next(p, nbm, nbn, smem);
+      next.template issue<0, Issue::COUNT>();
+    }
+    if (stats_stale) tile_rstd_compute<BM>(epi.rsc, rs, m0, tid, aux);
+    typedef const __attribute__((address_space(3))) f32x4* lds_cf32x4_t;
+    lds_cf32x4_t brow = (lds_cf32x4_t)(size_t)(unsigned)(size_t)(aux + rowscale_ssq_bytes<BM>(epi.rsc.tiles));
+    f32x4 bias[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bias[j] = brow[(wn * WN + j * 16 + ln) >> 2];
+    __syncthreads();   // rstd of the tile's rows visible; every lane holds its bias entries: the aux rows are free
+    if (more) operands(nbm, nbn, nbm != bm);
+    MSD_TS_AT(0, vcur, 4)
+    RangeCheck rc;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int r = wm * WM + i * 16 + lm;
+      const float rstd = rs[r];
+      const size_t orow = (size_t)(m0 + r) * epi.ldc + (n0 + wn * WN) / 2 + ln;
+#pragma unroll
+      for (int q = 0; q < FN / 2; ++q) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h0 = __builtin_fmaf(acc.a[i][2 * q][e] * kWScaleInv, rstd, bias[2 * q][e]);
+          const float h1 = __builtin_fmaf(acc.a[i][2 * q + 1][e] * kWScaleInv, rstd, bias[2 * q + 1][e]);
+          o[e] = gelu_tanh(h0) * h1;
+        }
+        store_h16x4<NP>(epi.out, orow + q * 16, o, rc);
+      }
+    }
+    rc.commit(p.sat, p.sat_tag);
+    MSD_TS_AT(0, vcur, 5)
+    MSD_TS_AT(0, vcur, 6)
+#if MSD_TIMESTAMPS
+    if (threadIdx.x == 0 && vcur < kTsBlocks) {
+      g_msd_ts[0][vcur][9] = (unsigned long long)vblocks;
+      g_msd_ts[0][vcur][11] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (!more) break;
+    stats_stale = nbm != bm;
+    bm = nbm; bn = nbn;
+  }
+}
+
+template <int NP, int BM, int BN, int NS>
+inline hipError_t gemm_h16_geglu_persist_prepare() {
+  constexpr int smem = gemm_h16_geglu_persist_smem<NP, BM, BN, NS>();
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_geglu_persist_kernel<NP, BM, BN, NS, 0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h16_geglu_persist_kernel<NP, BM, BN, NS, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  return e != hipSuccess ? e : r;
+}
+
+// `blocks`: resident blocks to launch (a multiple of 8, at most one per CU)
+template <int NP, int BM, int BN, int NS>
+inline hipError_t launch_gemm_h16_geglu_persist(const GemmParams& p_in, const EpiGeglu<NP>& epi, int blocks, hipStream_t stream) {
+  static_assert(NP == 2, "two-plane modes");
+  constexpr int smem = gemm_h16_geglu_persist_smem<NP, BM, BN, NS>();
+  static const hipError_t attr = gemm_h16_geglu_persist_prepare<NP, BM, BN, NS>();
+  if (attr != hipSuccess) return attr;
+  if (!epi.rsc.ssq || !epi.rsc.bias || p_in.K < NS * kGemmBK) return hipErrorInvalidValue;
+  GemmParams p = p_in;
+  p.map.fill(p.M, p.N, BM, BN, p.xcd_rows);
+  const int rx = p.xcd_rows, cx = 8 / rx;
+  const int vblocks = 8 * ((p.N / BN + cx - 1) / cx) * ((p.M / BM + rx - 1) / rx);
+  const int grid = vblocks < blocks ? vblocks : blocks;
+  if (prefetch_kind(p.pf) >= 1)
+    hipLaunchKernelGGL((gemm_h16_geglu_persist_kernel<NP, BM, BN, NS, 1>), dim3(grid), dim3(256 + pf_threads(1)), smem, stream, p, epi, vblocks);
+  else
+    hipLaunchKernelGGL((gemm_h16_geglu_persist_kernel<NP, BM, BN, NS, 0>), dim3(grid), dim3(256), smem, stream, p, epi, vblocks);
   return hipGetLastError();
 }
 

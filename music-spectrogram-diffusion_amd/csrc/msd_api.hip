@@ -163,6 +163,7 @@ struct msd_model {
   int kv_touch_ahead = 2;      // attention.h kv_touch_ahead: stages the prefetch wave runs in front of the K / V^T ring (0 = off)
   bool merge_in_launch = true; // attention.h attention_inlaunch_merge (msd_config.cross_merge_in_launch = 2 turns it off)
   bool fold_q = true;          // folded cross-attention query projection (msd_config.cross_q_fold = 2 turns it off)
+  bool persist_mlp_in = true;  // batched songs: persistent gated-MLP-in tile loop (msd_config.mlp_in_persistent = 2 turns it off)
   Planes xg;                   // [Bmax T, D] x (.) gamma_cross of the layer about to run, conditional rows (EpiResidualNorm Y2)
   float* qp = nullptr;         // [Bmax T, n_cross J] (x0 (.) gamma) . Wq, the half of the projection that rides on the QKV launch
   int* att_tickets = nullptr;  // its arrival counters: [Bmax][T / 32][H], zero between launches
@@ -498,6 +499,22 @@ void gemm(Ctx& c, int kc, const Planes& a, int lda, const Planes& b, int ldb, in
     MSD_GO(64, 64, wide_ns(NP));
   } else if constexpr (TK == TK_MLP_IN) {
     if constexpr (NP == 2) {
+      if constexpr (std::is_same<Epi, EpiGeglu<NP>>::value) {
+        // batched songs, decoder MLP blocks: the persistent tile loop with the register epilogue (gemm_h16.h) -- one
+        // resident block per CU walks its 4 .. 8 tiles, the next tile's ring stages land under the current epilogue
+        if (t.bm == 128 && c.m->persist_mlp_in && epi.rsc.ssq && epi.rsc.bias && K >= 2 * kGemmBK) {
+          c.begin(kc);
+          GemmParams p = gp<NP>(a, lda, b, ldb, M, N, K);
+          if (pf) p.pf = *pf;
+          p.sat = c.m->d_sat; p.sat_tag = (unsigned)kc + 1u;
+          set_xcd_grid(c.m, p, kc, M, 128);
+          const int cus = c.m->cus > 0 ? c.m->cus : 256;
+          hipError_t e = launch_gemm_h16_geglu_persist<NP, 128, 128, 2>(p, epi, cus / 8 * 8, c.s);
+          if (e != hipSuccess && c.err == hipSuccess) c.err = e;
+          c.end(kc);
+          return;
+        }
+      }
       if (t.bm == 128) MSD_GO_BIG(128, 128)
       if (t.bn == 128) MSD_GO(64, 128, 3);
     }
@@ -545,6 +562,7 @@ hipError_t prepare_gemms() {
     PREP(128, 96, 2, EpiResidual) PREP(128, 96, 2, EpiResidualNorm<NP>) PREP(128, 96, 2, EpiStoreH16<NP>)
     PREP(64, 96, 3, EpiResidual) PREP(64, 96, 3, EpiResidualNorm<NP>) PREP(64, 96, 3, EpiStoreH16<NP>)
     { using EpiDup = EpiResidualNorm<NP, true>; PREP(128, 96, 2, EpiDup) PREP(64, 96, 3, EpiDup) }
+    if ((r = gemm_h16_geglu_persist_prepare<NP, 128, 128, 2>()) != hipSuccess) e = r;
     PREP(32, kWide48, 4, EpiResidualNorm<NP>)
   }
   PREP(32, 32, 4, EpiResidual) PREP(32, 32, 4, EpiResidualNorm<NP>) PREP(32, 32, 4, EpiStoreH16<NP>)
@@ -1392,6 +1410,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->kv_touch_ahead < -1 || cfg->kv_touch_ahead > 16) return bad("kv_touch_ahead must be 0 (library default), -1 (off) or 1 .. 16 stages");
   if (cfg->cross_merge_in_launch < 0 || cfg->cross_merge_in_launch > 2) return bad("cross_merge_in_launch must be 0 (library default), 1 (on) or 2 (off)");
   if (cfg->cross_q_fold < 0 || cfg->cross_q_fold > 2) return bad("cross_q_fold must be 0 (library default), 1 (on) or 2 (off)");
+  if (cfg->mlp_in_persistent < 0 || cfg->mlp_in_persistent > 2) return bad("mlp_in_persistent must be 0 (library default), 1 (on) or 2 (off)");
   {  // schedule / model_output / logvar_type combinations are validated by building the table once
     std::vector<float> rows;
     std::string why;
@@ -1409,6 +1428,7 @@ int msd_create(const msd_config* cfg, msd_model** out) {
   if (cfg->kv_touch_ahead) m->kv_touch_ahead = cfg->kv_touch_ahead < 0 ? 0 : cfg->kv_touch_ahead;
   m->merge_in_launch = cfg->cross_merge_in_launch != 2;
   m->fold_q = cfg->cross_q_fold != 2 && m->NP == 2;
+  m->persist_mlp_in = cfg->mlp_in_persistent != 2;
   {
     // Query-side planes of the decoder's attentions (attention.h QP bit 0: Q one plane, bit 1: P one plane).  Library
     // default with half planes in the two-plane mode: kDefaultQPlanes / kDefaultPPlanes (the sharp-

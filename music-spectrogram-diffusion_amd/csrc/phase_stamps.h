@@ -36,7 +36,7 @@ template <int BM, int BN> constexpr int ts_class() { return BN == 128 ? 0 : (BN 
       g_msd_ts[CLS][BLK][11] = __builtin_amdgcn_s_memrealtime();                                         \
     }                                                                                                    \
   }
-#define MSD_TS_STAMP(BM_, BN_, FIELD) MSD_TS_AT((ts_class<BM_, BN_>()), blockIdx.x, FIELD)
+#define MSD_TS_STAMP(BM_, BN_, FIELD) MSD_TS_AT((ts_class<BM_, BN_>()), msd_ts_blk, FIELD)   /* msd_ts_blk: the enclosing gemm_tile's record */
 #else
 #define MSD_TS_AT(CLS, BLK, FIELD)
 #define MSD_TS_BEGIN(CLS, BLK)

@@ -79,7 +79,7 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
                       weight_prefetch: Optional[bool] = None, dedup_layer0: Optional[bool] = None,
                       cross_key_split: int = 0, keep_raw_weights: bool = False,
                       kv_touch_ahead: Optional[int] = None, cross_merge_in_launch: Optional[bool] = None,
-                      cross_q_fold: Optional[bool] = None) -> native.MsdConfig:
+                      cross_q_fold: Optional[bool] = None, mlp_in_persistent: Optional[bool] = None) -> native.MsdConfig:
   t5, d = spec.t5, spec.diffusion
   # Everything the kernels fix by construction is validated here with the
   # reference's own error type (ValueError; msd_amd.h msd_config comment).
@@ -174,6 +174,7 @@ def _to_native_config(spec: config_lib.ModelSpec, codec: audio_codecs.AudioCodec
   cfg.kv_touch_ahead = 0 if kv_touch_ahead is None else (-1 if int(kv_touch_ahead) == 0 else int(kv_touch_ahead))
   cfg.cross_merge_in_launch = 0 if cross_merge_in_launch is None else (1 if cross_merge_in_launch else 2)
   cfg.cross_q_fold = 0 if cross_q_fold is None else (1 if cross_q_fold else 2)
+  cfg.mlp_in_persistent = 0 if mlp_in_persistent is None else (1 if mlp_in_persistent else 2)
   return cfg
 
 
@@ -212,7 +213,8 @@ class InferenceModel(object):
                range_fallback: bool = True, attention_query_planes=None, graph_steps: int = 0,
                weight_prefetch: Optional[bool] = None, dedup_layer0: Optional[bool] = None,
                cross_key_split: int = 0, keep_raw_weights: bool = False, kv_touch_ahead: Optional[int] = None,
-               cross_merge_in_launch: Optional[bool] = None, cross_q_fold: Optional[bool] = None):
+               cross_merge_in_launch: Optional[bool] = None, cross_q_fold: Optional[bool] = None,
+               mlp_in_persistent: Optional[bool] = None):
     """Args mirror inference.py:71-88.
 
     gin_config: the parsed gin string (``parse_training_gin_file``) or a typed
@@ -238,6 +240,8 @@ class InferenceModel(object):
       the partials; no merge launch); None = the library's choice, False = the separate merge launch.  Bit-identical.
     cross_q_fold: the cross-attention's query projection has no launch of its own (folded into the QKV and the
       self-attention output projection launches by exact algebra, msd_amd.h); None = the library's choice (on)
+    mlp_in_persistent: batched songs (>= 4 per call): the decoder's gated-MLP input projection as one resident block per
+      CU walking its tiles (register epilogue, the next tile's operands land under it); None = the library's choice (on)
     keep_raw_weights: keep the float32 staging copies of the packed matrices on the device (default: freed after
       packing -- 1.5 GB per handle at base_with_context).
     range_fallback: what to do when an activation leaves the range of the half planes (|x| > 65504; the
@@ -263,6 +267,7 @@ class InferenceModel(object):
     self.dedup_layer0, self.cross_key_split, self.keep_raw_weights = dedup_layer0, cross_key_split, keep_raw_weights
     self.kv_touch_ahead = kv_touch_ahead
     self.cross_merge_in_launch, self.cross_q_fold = cross_merge_in_launch, cross_q_fold
+    self.mlp_in_persistent = mlp_in_persistent
 
     self.sequence_length = dict(spec.task_feature_lengths)
     self.inputs_length = self.sequence_length['inputs']
@@ -330,7 +335,7 @@ class InferenceModel(object):
         cfg = _to_native_config(self.spec, self.audio_codec, self.batch_size, self.precision,
                                 self.attention_query_planes, self.graph_steps, self.weight_prefetch,
                                 self.dedup_layer0, self.cross_key_split, self.keep_raw_weights, self.kv_touch_ahead,
-                                self.cross_merge_in_launch, self.cross_q_fold)
+                                self.cross_merge_in_launch, self.cross_q_fold, self.mlp_in_persistent)
         nm = native.NativeModel(cfg)   # the library build (plane format) follows from cfg.precision
         self._stream = torch.cuda.Stream(device=self.device)
         nm.load_weights(params, stream=self._stream.cuda_stream)

@@ -90,7 +90,8 @@ class MsdConfig(ctypes.Structure):
       ('weight_prefetch', ctypes.c_int32),
       ('dedup_layer0', ctypes.c_int32), ('cross_key_split', ctypes.c_int32), ('keep_raw_weights', ctypes.c_int32),
       ('kv_touch_ahead', ctypes.c_int32),
-      ('cross_merge_in_launch', ctypes.c_int32), ('cross_q_fold', ctypes.c_int32)]
+      ('cross_merge_in_launch', ctypes.c_int32), ('cross_q_fold', ctypes.c_int32),
+      ('mlp_in_persistent', ctypes.c_int32)]
 
 
 # msd_config only ever grows at its end, so an OLDER library can be driven by passing it the struct size it knows

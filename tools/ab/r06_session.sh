@@ -62,6 +62,12 @@ seventh)  # fold: full GPU suite + small / 2 / 3 songs A/B
   timeout 400 python tools/ab/knob_ab.py --rounds 3 --batch 2 --steps 500 --tokens 900 --json $OUT/${TAG}_fold_ab_b2.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_b2.log
   timeout 400 python tools/ab/knob_ab.py --rounds 3 --batch 3 --steps 300 --tokens 900 --json $OUT/${TAG}_fold_ab_b3.json 'cross_q_fold=False' 'cross_q_fold=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_fold_ab_b3.log
   ;;
+eighth)  # persistent gated-MLP-in at batch: parity test + A/B at 4 / 8 / 16 songs
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "batched_songs" > $OUT/${TAG}_batched_test.log 2>&1; tail -3 $OUT/${TAG}_batched_test.log
+  for nb in 8 4 16; do
+    timeout 500 python tools/ab/knob_ab.py --rounds 3 --batch $nb --steps 120 --tokens 900 --json $OUT/${TAG}_persist_ab_b$nb.json 'mlp_in_persistent=False' 'mlp_in_persistent=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_persist_ab_b$nb.log
+  done
+  ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20

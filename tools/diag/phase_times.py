@@ -60,7 +60,9 @@ def pct(v):
 def main():
   steps, nb = int(os.environ.get('STEPS', '16')), int(os.environ.get('BATCH', '1'))
   spec = msd_amd.config.preset('base_with_context', num_steps=steps)
-  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb)
+  import ast
+  kw = {k.strip(): ast.literal_eval(v.strip()) for k, v in (it.split('=', 1) for it in os.environ.get('KNOB', '').split(',') if it.strip())}
+  model = msd_amd.InferenceModel('synthetic:0', spec, batch_size=nb, **kw)   # KNOB='mlp_in_persistent=False,...': InferenceModel keywords
   batch = helpers.make_batch(spec, batch=nb)
   init_z, noise = helpers.make_noise(spec, batch=nb)
   print('base_with_context, %d song(s) per handle, %d steps' % (nb, steps))
