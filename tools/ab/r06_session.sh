@@ -68,6 +68,24 @@ eighth)  # persistent gated-MLP-in at batch: parity test + A/B at 4 / 8 / 16 son
     timeout 500 python tools/ab/knob_ab.py --rounds 3 --batch $nb --steps 120 --tokens 900 --json $OUT/${TAG}_persist_ab_b$nb.json 'mlp_in_persistent=False' 'mlp_in_persistent=True' 2>&1 | grep -v Warning | tee $OUT/${TAG}_persist_ab_b$nb.log
   done
   ;;
+final)   # the round's record: tests + smoke + kernel trace + counter passes + stamps + default bench, ONE binary
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile.log 2>&1; tail -4 $OUT/${TAG}_profile.log
+  PRESET=small SKIP_TRACE=1 bash tools/profile_round.sh ${TAG}_small > $OUT/${TAG}_small_profile.log 2>&1; tail -2 $OUT/${TAG}_small_profile.log
+  TS=$ROOT/tools/ubench/exp/libmsd_amd_ts.so   # the same sources with -DMSD_TIMESTAMPS=1
+  if [ -f $TS ]; then
+    MSD_AMD_LIB=$TS timeout 200 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times.txt 2>&1; tail -3 $OUT/${TAG}_phase_times.txt
+    BATCH=8 MSD_AMD_LIB=$TS timeout 300 python tools/diag/phase_times.py > $OUT/${TAG}_phase_times_b8.txt 2>&1; tail -3 $OUT/${TAG}_phase_times_b8.txt
+  fi
+  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b8
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b8 -- \
+      python $ROOT/bench.py --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --no-self-profile --batched-songs 0 --small-segments 0 --profile-steps 1 > $OUT/${TAG}_bench_b8_under_rocprof.json 2>/dev/null
+  find /tmp/prof_b8 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_b8_kernel_stats.csv
+  cd $ROOT
+  mkdir -p $OUT/${TAG}_selfprof
+  timeout 900 python bench.py --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 1200 $OUT/${TAG}_bench_default.json
+  ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20

@@ -128,6 +128,7 @@ def main():
   for e in out.values():
     e['avg_us'] = round(e.pop('_ns') / e['calls'] / 1e3, 3)
     e['kernel'] = ' | '.join(e['kernel'])
+  bench.fold_cross_q_work(flops, abytes, out)   # round 6 (S6): no cross-q launch -- its algorithmic work sits with attention-out
 
   def pmc(name):
     path = os.path.join(prof, '%s_pmc_%s.csv' % (pmc_tag, name))
