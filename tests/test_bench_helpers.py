@@ -207,3 +207,29 @@ def test_kernel_trace_classes_by_position_in_the_step(tmp_path):
 
 def test_watchdog_exit_code_is_a_failure():
   assert bench.Watchdog.EXIT_CODE != 0
+
+
+def test_dual_launch_kernels_classify_and_carry_the_folded_query_projection():
+  """Round 6 (S6): the QKV and attention-out launches are `gemm_h16_dual_kernel`s (two problems, each with its own tile
+  shape); the cross-attention's query projection has no launch of its own and its ALGORITHMIC work is counted with the
+  attention-out launch, once -- in the bench line's per-class table and in tools/make_roofline.py alike."""
+  import bench
+  qkv = ('void msd::gemm_h16_dual_kernel<2, 64, 96, 3, msd::EpiQKV<2>, 64, 96, 3, msd::EpiStoreF32, 1>'
+         '(msd::GemmParams, msd::EpiQKV<2>, msd::GemmParams, msd::EpiStoreF32, int)')
+  qkv0 = qkv.replace('64, 96, 3', '64, 64, 3')
+  out = ('void msd::gemm_h16_dual_kernel<2, 64, 32, 4, msd::EpiResidualNorm<2, false, false>, 32, 96, 4, msd::EpiAddStoreH16<2>, 0>'
+         '(msd::GemmParams, msd::EpiResidualNorm<2, false, false>, msd::GemmParams, msd::EpiAddStoreH16<2>, int)')
+  out0 = out.replace('64, 32, 4, msd::EpiResidualNorm<2, false, false>', '32, 32, 4, msd::EpiResidualNorm<2, true, false>')
+  mlp_out_y2 = 'void msd::gemm_h16_dma_kernel<2, 32, 48, 4, msd::EpiResidualNorm<2, false, true>, 1>(msd::GemmParams, msd::EpiResidualNorm<2, false, true>)'
+  step = {bench.normalise_kernel(k) for k in (qkv, qkv0, out, out0, mlp_out_y2)}
+  assert bench.classify_kernel(qkv, step) == 'gemm_qkv' and bench.classify_kernel(qkv0, step) == 'gemm_qkv_l0'
+  assert bench.classify_kernel(out, step) == 'gemm_attn_out' and bench.classify_kernel(out0, step) == 'gemm_attn_out_l0'
+  assert bench.classify_kernel(mlp_out_y2, step) == 'gemm_mlp_out'
+  assert bench.kernel_type(qkv) == 'qkv' and bench.kernel_type(out) == 'resid' and bench.kernel_type(mlp_out_y2) == 'resid'
+  flops = {'gemm_attn_out': 10.0, 'gemm_attn_out_l0': 5.0, 'gemm_cross_q': 3.0, 'gemm_qkv': 30.0}
+  abytes = {'gemm_attn_out': 100, 'gemm_cross_q': 30}
+  bench.fold_cross_q_work(flops, abytes, {'gemm_attn_out': {}, 'gemm_attn_out_l0': {}, 'gemm_qkv': {}})   # no cross-q launch: folded
+  assert flops['gemm_attn_out'] == 13.0 and flops['gemm_attn_out_l0'] == 8.0 and abytes['gemm_attn_out'] == 130
+  flops2 = {'gemm_attn_out': 10.0, 'gemm_cross_q': 3.0}
+  bench.fold_cross_q_work(flops2, {}, {'gemm_attn_out': {}, 'gemm_cross_q': {}})                           # a launch of its own: untouched
+  assert flops2['gemm_attn_out'] == 10.0
