@@ -86,6 +86,11 @@ final)   # the round's record: tests + smoke + kernel trace + counter passes + s
   mkdir -p $OUT/${TAG}_selfprof
   timeout 900 python bench.py --self-profile-keep $OUT/${TAG}_selfprof > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; tail -c 1200 $OUT/${TAG}_bench_default.json
   ;;
+driver)   # what the driver runs at round end, on one fresh box: the -m gpu suite (-x), smoke, the default bench
+  timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_tests.log 2>&1; tail -3 $OUT/${TAG}_gpu_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; tail -2 $OUT/${TAG}_smoke.log
+  T0=$(date +%s); timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench wall $(( $(date +%s) - T0 )) s" | tee -a $OUT/${TAG}_bench_default.err; tail -c 900 $OUT/${TAG}_bench_default.json; tail -2 $OUT/${TAG}_bench_default.err
+  ;;
 tests)
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; tail -6 $OUT/${TAG}_gpu_tests.log
   grep -E "^FAILED|^ERROR" $OUT/${TAG}_gpu_tests.log | head -20
