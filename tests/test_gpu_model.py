@@ -276,6 +276,17 @@ def test_batched_songs_use_big_tiles_and_match_oracle():
   ref64, _ = _oracle(spec, params, batch, init_z, noise, 'float64')
   ref32, _ = _oracle(spec, params, batch, init_z, noise, 'float32')
   helpers.assert_fp32_class(got, ref64, ref32, what='batched B=16')
+  # round 6: the gated-MLP input projection of that run was the PERSISTENT tile loop with the register epilogue
+  # (msd_config.mlp_in_persistent, gemm_h16.h gemm_h16_geglu_persist_kernel: M = 2048 rows of 128 x 128 tiles, several per
+  # block at this size); the per-tile launch it replaces must land in the same class -- same function, another
+  # contraction of the epilogue's multiply-adds
+  plain = msd_amd.InferenceModel(params, spec, batch_size=B, mlp_in_persistent=False, **helpers.ALL_PLANES)
+  got_plain, _ = plain.predict(batch, init_z=init_z, noise=noise)
+  helpers.assert_fp32_class(got_plain, ref64, ref32, what='batched B=16, per-tile MLP-in launch')
+  d = np.asarray(got, np.float64) - np.asarray(got_plain, np.float64)
+  print('batched B=16: persistent vs per-tile MLP-in: median |diff| %.2e, max %.2e' % (np.median(np.abs(d)), np.abs(d).max()))
+  assert np.median(np.abs(d)) < 1e-5
+  del plain
   # and one decoder pass, elementwise (no chaotic amplification)
   import torch
   from oracle import backend, fast
