@@ -60,6 +60,14 @@ struct AttnParams {
   int allow_qb4 = 0;         // host only: this launch may run on 128-row blocks (attention_query_blocks)
   int touch_ahead = 0;       // > 0 (launches with a prefetch wave only): that wave also touches the K / V^T lines of the
                              // block's ring stages this many stages AHEAD of their LDS-DMA (kv_touch_ahead below)
+  int pf_late = 0;           // touch-ahead launches only (round 6): the prefetch wave issues NOTHING at entry -- its touches of
+                             // the launch's weight target and of the ring stages NS .. NS + ahead - 1 go out behind the
+                             // first key-loop barrier (stage 0 has landed).  At entry they competed with every block's
+                             // first two K / V^T stages (192 x 128 KiB) for the same HBM burst: the launch 14.2 -> 13.5 us
+                             // at 1136 cold keys for the weights alone (tools/ubench/attn_cold.hip); step, same process:
+                             // weights late -0.9 ... -1.2 %, the stage touches late another -0.5 ... -1.1 % from ~1150 keys,
+                             // 0 at 557 (profiles/r06q_pf_place_ab*.log).  The weights still arrive a launch ahead of
+                             // their GEMM.  Bit-identical (a touch has no reader).
   int* tickets = nullptr;    // ksplit > 1, in-launch merge (round 6, attention_inlaunch_merge below): one arrival counter per
                              // (segment, query block of this launch, head), all zero between launches; nullptr = the
                              // separate attention_merge_kernel launch finishes the split
@@ -118,8 +126,9 @@ __host__ __device__ inline int attention_query_blocks(int blocks64, int q_rows_p
 // key loop runs at 2.5 us per stage where the MFMAs need 0.65 (profiles/r04z_phase_times*.txt; at 8 songs per handle a
 // block walks 11 stages: 62 of a layer's 320 us).  More ring does not fit the LDS; the L2 does hold a few stages per
 // block.  So the prefetch wave -- whose vmcnt nobody waits for -- touches one dword per 128-byte line of the stages
-// `ahead` (> 0) stages in front of the LDS-DMA front: stages NS .. NS + ahead - 1 at entry, then one more stage per key-loop
-// barrier, which it takes part in (an alive wave counts at s_barrier: it executes exactly the compute waves' barriers --
+// `ahead` (> 0) stages in front of the LDS-DMA front: stages NS .. NS + ahead - 1 first (at entry in round 5; behind the
+// first key-loop barrier since round 6, AttnParams::pf_late), then one more stage per key-loop barrier, which it takes part
+// in (an alive wave counts at s_barrier: it executes exactly the compute waves' barriers --
 // one per stage of this block + the two of the merge -- and ends).  The DMA of such a stage then finds its lines in the
 // XCD's L2 / the memory-side cache.  Same bytes from HBM, earlier; results are untouched (nobody reads a touch).
 // A touch is ONE DWORD PER LANE BY LDS-DMA into 256 bytes of LDS nobody reads (`sink_lds`, behind the block's working
@@ -165,14 +174,21 @@ __device__ __forceinline__ void kv_touch_ahead(const AttnParams& p, char* sink_l
       }
     }
   };
-  for (int st = NS; st < NS + ahead && st < nst; ++st) touch_stage(st);
-  {   // the launch's weight target (a later GEMM's planes), as before
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (!p.pf_late) for (int st = NS; st < NS + ahead && st < nst; ++st) touch_stage(st);
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  bool weights_done = false;
+  if (!p.pf_late || nst == 0) {   // the launch's weight target (a later GEMM's planes) at entry, as before
     prefetch_wave<PF, true>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], sink_lds);
+    weights_done = true;
   }
   {
     for (int st = 0; st < nst; ++st) {
       __builtin_amdgcn_s_barrier();                 // the compute waves' barrier of stage st
+      if (st == 0 && p.pf_late) for (int s2 = NS; s2 < NS + ahead && s2 < nst; ++s2) touch_stage(s2);
+      if (!weights_done) {                          // (pf_late) stage 0 is in LDS: the first K / V^T burst is over
+        prefetch_wave<PF, true>(p.pf, lin, gridDim.x * gridDim.y * gridDim.z, p.q[0], sink_lds);
+        weights_done = true;
+      }
       if (st + NS + ahead < nst) touch_stage(st + NS + ahead);
     }
     __builtin_amdgcn_s_barrier();                   // ... and the two of their partial merge

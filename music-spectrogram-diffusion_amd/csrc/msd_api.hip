@@ -641,6 +641,7 @@ void attention(Ctx& c, int kc, const Planes& q, int ldq, const h16_t* const k[2]
   // 2 songs +1.1 %, 4 songs +3.5 %, 8 songs +3.1 % -- batched launches are bandwidth-bound and the touches only add
   // requests -- so the library turns it on for one song only, whatever msd_config.kv_touch_ahead asks for beyond that.
   p.touch_ahead = (kc == KC_ATTN_CROSS && segs == 1) ? c.m->kv_touch_ahead : 0;
+  p.pf_late = 1;   // (such a launch's prefetch wave holds its touches back until the block's first stage has landed: attention.h)
   // 128-row blocks (attention.h attention_query_blocks) for the DECODER's attentions at batch: the cross-attention, and
   // the self-attention when its caller has taken the weight target off the launch (an empty, non-null prefetch)
   p.allow_qb4 = kc == KC_ATTN_CROSS || (kc == KC_ATTN_SELF && pf != nullptr && pf->n == 0);
